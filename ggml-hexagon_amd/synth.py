@@ -1,0 +1,49 @@
+"""Synthetic quantized weights in GGUF wire layout (rows of blocks), without running a quantizer.
+
+The hot path never quantizes weights (llama-quantize does that offline), so the bench and the
+full-size tests fill weight tensors with random *valid* blocks: random quant bytes and packed
+scales, fp16 super-scales drawn so that the dequantized values look like N(0, ~0.02) model
+weights (both signs of ``d`` occur, as the real quantizers produce).  Layouts: SURVEY.md Appendix A
+(ggml/src/ggml-common.h:167-172, 209-214, 285-334).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+Q4_0, Q8_0, Q4_K, Q5_K, Q6_K = 2, 8, 12, 13, 14
+BLCK = {Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256}
+TYPE_SIZE = {Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210}
+NAMES = {Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K"}
+BY_NAME = {v: k for k, v in NAMES.items()}
+
+
+def row_size(t: int, k: int) -> int:
+    assert k % BLCK[t] == 0
+    return k // BLCK[t] * TYPE_SIZE[t]
+
+
+def _f16_bytes(rng, n, scale, signed=True):
+    v = rng.uniform(0.5, 1.5, n).astype(np.float32) * scale
+    if signed:
+        v *= rng.choice(np.array([-1.0, 1.0], np.float32), n)
+    return v.astype(np.float16).view(np.uint8).reshape(n, 2)
+
+
+def synth_weights(t: int, rows: int, k: int, seed: int = 0, sigma: float = 0.02) -> np.ndarray:
+    """uint8 [rows, row_size(t,k)] of random valid blocks."""
+    rng = np.random.default_rng(seed)
+    nb = rows * (k // BLCK[t])
+    blk = rng.integers(0, 256, (nb, TYPE_SIZE[t]), dtype=np.uint8)
+    if t == Q4_0:
+        blk[:, 0:2] = _f16_bytes(rng, nb, 3 * sigma / 8)
+    elif t == Q8_0:
+        blk[:, 0:2] = _f16_bytes(rng, nb, 3 * sigma / 127)
+    elif t in (Q4_K, Q5_K):
+        qmax = 15 if t == Q4_K else 31
+        blk[:, 0:2] = _f16_bytes(rng, nb, 6 * sigma / qmax / 40, signed=False)   # d   (sub-scale ~ d*sc, sc<=63)
+        blk[:, 2:4] = _f16_bytes(rng, nb, 3 * sigma / 40, signed=False)          # dmin (offset ~ dmin*m)
+    elif t == Q6_K:
+        blk[:, 208:210] = _f16_bytes(rng, nb, 3 * sigma / 32 / 80)
+    else:
+        raise ValueError(t)
+    return blk.reshape(rows, -1)

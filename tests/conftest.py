@@ -1,0 +1,37 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.pyoracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """the real reference (oracle/_ref) when it has been built; tests that need it skip otherwise"""
+    from oracle.pyoracle import RefGgml, ref_available
+    if not ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference; run `make -C oracle ref`)")
+    return RefGgml("avx2")
+
+
+GOLDEN = ROOT / "tests" / "golden"
+TYPES = ["q4_0", "q8_0", "q4_K", "q5_K", "q6_K"]
+
+
+@pytest.fixture(scope="session", params=TYPES)
+def golden(request):
+    import numpy as np
+    return np.load(GOLDEN / f"golden_{request.param}.npz")
