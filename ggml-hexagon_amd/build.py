@@ -1,0 +1,70 @@
+"""hipcc build recipes (gfx950 only, in-tree outputs so the .so files travel with gpurun snapshots)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+QMM_SO = PKG / "libggml_mi355x_qmm.so"
+PLUGIN_SO = PKG / "libggml-mi355x.so"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+GGML_SRC = Path(os.environ.get("GGML_SRC_DIR", "/root/reference/ggml"))
+
+
+def _newer(target: Path, sources) -> bool:
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(Path(s).stat().st_mtime <= t for s in sources)
+
+
+def build_qmm(force: bool = False) -> Path:
+    """the kernel library behind include/ggml_mi355x_qmm.h"""
+    srcs = sorted(CSRC.glob("qmm_*")) + [ROOT / "include" / "ggml_mi355x_qmm.h"]
+    if not force and _newer(QMM_SO, srcs):
+        return QMM_SO
+    if not shutil.which(HIPCC):
+        if QMM_SO.exists():
+            return QMM_SO
+        raise RuntimeError("hipcc not found and no prebuilt libggml_mi355x_qmm.so")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-o", str(QMM_SO), str(CSRC / "qmm_api.hip")]
+    subprocess.run(cmd, check=True)
+    return QMM_SO
+
+
+def have_ggml_headers() -> bool:
+    return (GGML_SRC / "include" / "ggml-backend.h").exists() and (GGML_SRC / "src" / "ggml-backend-impl.h").exists()
+
+
+def build_plugin(force: bool = False) -> Path | None:
+    """the ggml backend plugin (GGML_BACKEND_DL module).  It is compiled against the ggml headers of the
+    llama.cpp tree it will be loaded into (here: the reference tree, in place); when that tree is not
+    present the prebuilt module, if any, is kept."""
+    src = CSRC / "ggml-mi355x.cpp"
+    if not src.exists():
+        return None
+    srcs = [src, ROOT / "include" / "ggml-mi355x.h", ROOT / "include" / "ggml_mi355x_qmm.h"]
+    if not force and _newer(PLUGIN_SO, srcs + [QMM_SO]):
+        return PLUGIN_SO
+    if not have_ggml_headers() or not shutil.which(HIPCC):
+        return PLUGIN_SO if PLUGIN_SO.exists() else None
+    cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-DGGML_BACKEND_DL", "-DGGML_BACKEND_BUILD", "-DGGML_BACKEND_SHARED",
+           "-DGGML_SHARED", "-D__HIP_PLATFORM_AMD__",
+           f"-I{GGML_SRC / 'include'}", f"-I{GGML_SRC / 'src'}", f"-I{ROOT / 'include'}", "-I/opt/rocm/include",
+           "-x", "c++", str(src), "-o", str(PLUGIN_SO),
+           f"-L{PKG}", "-lggml_mi355x_qmm", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    return PLUGIN_SO
+
+
+def build_all(force: bool = False):
+    return build_qmm(force), build_plugin(force)
+
+
+if __name__ == "__main__":
+    print(build_all(force=True))

@@ -1,0 +1,156 @@
+"""ctypes binding of include/ggml_mi355x_qmm.h.  Device pointers in, device pointers out; torch is used by
+callers only to own HBM buffers and streams.  There is no fallback: if the HIP library cannot be loaded or
+the device is not gfx950, construction raises."""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import build as _build
+
+Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 2, 8, 12, 13, 14, 15
+ACT_REF, ACT_X86 = 0, 1
+PREC_BF16, PREC_F16_Q8 = 0, 1
+MATVEC_MAX_N = 8
+
+EXPORTS = [
+    "qmm_abi_version", "qmm_last_error", "qmm_device_count", "qmm_create", "qmm_destroy", "qmm_device", "qmm_stream",
+    "qmm_device_info", "qmm_set_act_mode", "qmm_set_precision", "qmm_malloc", "qmm_free", "qmm_memcpy_h2d",
+    "qmm_memcpy_d2h", "qmm_memcpy_d2d", "qmm_memset", "qmm_synchronize", "qmm_row_size", "qmm_dequantize",
+    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_id",
+]
+
+
+class QmmWeight(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("w_row_bytes", C.c_int64), ("M", C.c_int64), ("dst", C.c_void_p),
+                ("ldd", C.c_int64), ("type", C.c_int)]
+
+
+class QmmError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    so = _build.build_qmm()
+    lib = C.CDLL(str(so))
+    v, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+    lib.qmm_last_error.restype = C.c_char_p
+    lib.qmm_create.restype = v
+    lib.qmm_create.argtypes = [i32]
+    lib.qmm_destroy.argtypes = [v]
+    lib.qmm_device.argtypes = [v]
+    lib.qmm_stream.restype = v
+    lib.qmm_stream.argtypes = [v]
+    lib.qmm_device_info.argtypes = [v, C.c_char_p, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32)]
+    lib.qmm_set_act_mode.argtypes = [v, i32]
+    lib.qmm_set_precision.argtypes = [v, i32]
+    lib.qmm_malloc.restype = v
+    lib.qmm_malloc.argtypes = [v, sz]
+    lib.qmm_free.argtypes = [v, v]
+    for f in (lib.qmm_memcpy_h2d, lib.qmm_memcpy_d2h, lib.qmm_memcpy_d2d):
+        f.argtypes = [v, v, v, sz, v]
+    lib.qmm_memset.argtypes = [v, v, i32, sz, v]
+    lib.qmm_synchronize.argtypes = [v, v]
+    lib.qmm_row_size.restype = sz
+    lib.qmm_row_size.argtypes = [i32, i64]
+    lib.qmm_dequantize.argtypes = [v, i32, v, i64, i64, i64, v, v]
+    lib.qmm_quantize_act.argtypes = [v, i32, v, i64, i64, i64, v, v, v, v]
+    lib.qmm_mul_mat.argtypes = [v, i32, v, i64, i64, i64, v, i64, i64, v, i64, v]
+    lib.qmm_mul_mat_group.argtypes = [v, C.POINTER(QmmWeight), i32, i64, v, i64, i64, v]
+    lib.qmm_mul_mat_id.argtypes = [v, i32, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, i64, i64, v]
+    return lib
+
+
+class Qmm:
+    """One context per GPU (the analogue of the reference's cDSP session, ggml-hexagon.cpp:4821-4973)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.ctx = self.lib.qmm_create(device)
+        if not self.ctx:
+            raise QmmError(self.lib.qmm_last_error().decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.qmm_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise QmmError(f"qmm error {rc}: {self.lib.qmm_last_error().decode()}")
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def set_act_mode(self, m):
+        self._chk(self.lib.qmm_set_act_mode(self.ctx, m))
+
+    def set_precision(self, p):
+        self._chk(self.lib.qmm_set_precision(self.ctx, p))
+
+    def synchronize(self):
+        self._chk(self.lib.qmm_synchronize(self.ctx, self._stream()))
+
+    def row_size(self, t, k):
+        return self.lib.qmm_row_size(t, k)
+
+    # --- torch-tensor conveniences (uint8 weight tensors [M, row_bytes] on the GPU) ---------------
+    def dequantize(self, t, w, k):
+        import torch
+        rows = w.shape[0]
+        out = torch.empty((rows, k), dtype=torch.float32, device=w.device)
+        self._chk(self.lib.qmm_dequantize(self.ctx, t, w.data_ptr(), w.stride(0), rows, k, out.data_ptr(), self._stream()))
+        return out
+
+    def quantize_act(self, vec_dot_type, x):
+        import torch
+        rows, k = x.shape
+        qb = 32 if vec_dot_type == Q8_0 else 256
+        q = torch.empty((rows, k), dtype=torch.int8, device=x.device)
+        d = torch.empty((rows, k // qb), dtype=torch.float32, device=x.device)
+        bs = torch.zeros((rows, k // 16), dtype=torch.int16, device=x.device) if vec_dot_type == Q8_K else None
+        self._chk(self.lib.qmm_quantize_act(self.ctx, vec_dot_type, x.data_ptr(), rows, k, x.stride(0), q.data_ptr(),
+                                            d.data_ptr(), bs.data_ptr() if bs is not None else None, self._stream()))
+        return q, d, bs
+
+    def mul_mat(self, t, w, k, x, out=None):
+        """w uint8 [M, row_bytes]; x f32 [N, K] -> f32 [N, M]"""
+        import torch
+        m, n = w.shape[0], x.shape[0]
+        if out is None:
+            out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        self._chk(self.lib.qmm_mul_mat(self.ctx, t, w.data_ptr(), w.stride(0), k, m, x.data_ptr(), n, x.stride(0),
+                                       out.data_ptr(), out.stride(0), self._stream()))
+        return out
+
+    def mul_mat_group(self, weights, k, x, outs):
+        """weights: list of (type, w uint8 [M,row_bytes]); outs: list of f32 [N, M]"""
+        arr = (QmmWeight * len(weights))()
+        for i, ((t, w), o) in enumerate(zip(weights, outs)):
+            arr[i] = QmmWeight(w.data_ptr(), w.stride(0), w.shape[0], o.data_ptr(), o.stride(0), t)
+        self._chk(self.lib.qmm_mul_mat_group(self.ctx, arr, len(weights), k, x.data_ptr(), x.shape[0], x.stride(0), self._stream()))
+        return outs
+
+    def mul_mat_id(self, t, w, k, b, ids, out=None):
+        """w uint8 [n_expert, M, row_bytes]; b f32 [n_tokens, ne11, K]; ids int32 [n_tokens, n_used] (row-strided view ok)
+        -> f32 [n_tokens, n_used, M]"""
+        import torch
+        n_expert, m = w.shape[0], w.shape[1]
+        n_tokens, ne11 = b.shape[0], b.shape[1]
+        n_used = ids.shape[1]
+        assert ids.stride(1) == 1
+        if out is None:
+            out = torch.empty((n_tokens, n_used, m), dtype=torch.float32, device=b.device)
+        self._chk(self.lib.qmm_mul_mat_id(self.ctx, t, w.data_ptr(), w.stride(1), w.stride(0), k, m, n_expert,
+                                          b.data_ptr(), ne11, b.stride(1) * 4, b.stride(0) * 4,
+                                          ids.data_ptr(), n_used, n_tokens, ids.stride(0) * 4,
+                                          out.data_ptr(), out.stride(1) * 4, out.stride(0) * 4, self._stream()))
+        return out

@@ -1,0 +1,132 @@
+// qmm_act.cuh — activation quantizers (f32 -> Q8_0 / Q8_K fields) as device functions that write
+// through whatever pointers they are given: LDS inside the mat-vec kernel, global in the standalone
+// qmm_quantize_act kernel.  Bit-exact with the reference quantizers:
+//   Q8_0  quantize_row_q8_0_ref  ggml/src/ggml-quants.c:194-217        (QMM_ACT_REF)
+//         quantize_row_q8_0 AVX2 ggml/src/ggml-cpu/ggml-cpu-quants.c:806-870 (QMM_ACT_X86)
+//   Q8_K  quantize_row_q8_K_ref  ggml/src/ggml-quants.c:2479-2516
+// Device layout (structure of arrays): q int8 [K], d f32 [K/32 | K/256], bsum int16 [K/16].
+#pragma once
+
+#include "qmm_device.cuh"
+
+namespace qmm {
+
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
+    return (uint32_t) (a & 0xff) | ((uint32_t) (b & 0xff) << 8) | ((uint32_t) (c & 0xff) << 16) | ((uint32_t) (d & 0xff) << 24);
+}
+
+// One Q8_0 block (32 floats) is handled by 8 consecutive lanes, 4 floats each.
+// `v` = this lane's 4 values; `sub` = lane index within its group of 8 (only for the store slot).
+__device__ __forceinline__ void q8_0_block(const float4 v, int act_mode, uint32_t & packed, float & d_out) {
+#pragma clang fp contract(off)
+    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, WAVE));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, WAVE));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, WAVE));
+    const float d = __fdiv_rn(amax, 127.0f);
+    d_out = __half2float(__float2half_rn(d));                  // y[i].d = GGML_FP32_TO_FP16(d)
+    int q0, q1, q2, q3;
+    if (act_mode == 1) {                                       // x86: id = 127/amax, round half to even
+        const float id = amax != 0.0f ? __fdiv_rn(127.0f, amax) : 0.0f;
+        q0 = (int) rintf(__fmul_rn(v.x, id)); q1 = (int) rintf(__fmul_rn(v.y, id));
+        q2 = (int) rintf(__fmul_rn(v.z, id)); q3 = (int) rintf(__fmul_rn(v.w, id));
+    } else {                                                   // ref: id = 1/d, roundf (half away)
+        const float id = d != 0.0f ? __fdiv_rn(1.0f, d) : 0.0f;
+        q0 = (int) roundf(__fmul_rn(v.x, id)); q1 = (int) roundf(__fmul_rn(v.y, id));
+        q2 = (int) roundf(__fmul_rn(v.z, id)); q3 = (int) roundf(__fmul_rn(v.w, id));
+    }
+    packed = pack4(q0, q1, q2, q3);
+}
+
+// nearest_int (ggml-quants.c:372-377): two roundings.  hipcc's default -ffp-contract=fast would fuse the
+// caller's multiply into this add (even through __fmul_rn/__fadd_rn, which are plain operators in the HIP
+// headers) and change ties: contraction is switched off in these functions.
+__device__ __forceinline__ int magic_round(float prod) {
+#pragma clang fp contract(off)
+    const float t = prod + 12582912.0f;
+    return (int) (__float_as_uint(t) & 0x007fffffu) - 0x00400000;
+}
+
+// One Q8_K block (256 floats) is handled by a whole wave, lane l holding elements 4l..4l+3.
+// Returns the packed 4 int8; d_out (all lanes) ; bsum valid in lanes with (lane & 3) == 0 -> group lane/4.
+__device__ __forceinline__ void q8_K_block(const float4 v, int lane, uint32_t & packed, float & d_out, int & bsum) {
+#pragma clang fp contract(off)      // the product must round to f32 BEFORE the magic add (hipcc contracts __fmul_rn/__fadd_rn too)
+    // first element with the largest |x| decides the sign of the scale (strict '>' scan in the reference)
+    float best = fabsf(v.x), bval = v.x;
+    int   bidx = 4 * lane;
+    if (fabsf(v.y) > best) { best = fabsf(v.y); bval = v.y; bidx = 4 * lane + 1; }
+    if (fabsf(v.z) > best) { best = fabsf(v.z); bval = v.z; bidx = 4 * lane + 2; }
+    if (fabsf(v.w) > best) { best = fabsf(v.w); bval = v.w; bidx = 4 * lane + 3; }
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const float ob = __shfl_xor(best, off, WAVE);
+        const float ov = __shfl_xor(bval, off, WAVE);
+        const int   oi = __shfl_xor(bidx, off, WAVE);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bval = ov; bidx = oi; }
+    }
+    if (best == 0.0f) {            // reference: d = 0, qs = 0 (bsums left as they were; we define 0)
+        packed = 0; d_out = 0.0f; bsum = 0;
+        return;
+    }
+    const float iscale = __fdiv_rn(-127.0f, bval);
+    const int q0 = min(127, magic_round(__fmul_rn(iscale, v.x)));
+    const int q1 = min(127, magic_round(__fmul_rn(iscale, v.y)));
+    const int q2 = min(127, magic_round(__fmul_rn(iscale, v.z)));
+    const int q3 = min(127, magic_round(__fmul_rn(iscale, v.w)));
+    packed = pack4(q0, q1, q2, q3);
+    int s = q0 + q1 + q2 + q3;
+    s += __shfl_xor(s, 1, WAVE);
+    s += __shfl_xor(s, 2, WAVE);
+    bsum  = s;
+    d_out = __fdiv_rn(1.0f, iscale);
+}
+
+// Quantize `rows` activation rows of length K into (q, d, bsum).  All threads of the block take part;
+// the caller synchronizes afterwards.  ACT = T_Q8_0 or T_Q8_K.  Row r of x starts at x + r*ldx;
+// outputs for row r at q + r*K, d + r*(K/blk), bsum + r*(K/16).
+template <int ACT>
+__device__ __forceinline__ void quantize_rows(const float * __restrict__ x, int64_t ldx, int rows, int K, int act_mode,
+                                              int8_t * q, float * d, int16_t * bsum, int tid, int nthreads) {
+    if (ACT == T_Q8_0) {
+        const int per_row = K / 4;                               // float4 slots per row
+        const int total = rows * per_row;                        // multiple of 8
+        for (int i = tid; i < ((total + nthreads - 1) / nthreads) * nthreads; i += nthreads) {
+            const bool live = i < total;                         // keep the 8-lane groups converged
+            const int r = live ? i / per_row : 0, c = live ? i % per_row : 0;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) v = *reinterpret_cast<const float4 *>(x + (int64_t) r * ldx + 4 * c);
+            uint32_t p; float dd;
+            q8_0_block(v, act_mode, p, dd);
+            if (live) {
+                *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + 4 * c) = p;
+                if ((c & 7) == 0) d[(int64_t) r * (K / 32) + c / 8] = dd;
+            }
+        }
+    } else {
+        const int lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = nthreads / WAVE;
+        const int nb = K / 256;
+        for (int blk = wave; blk < rows * nb; blk += nwaves) {
+            const int r = blk / nb, b = blk % nb;
+            const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t) r * ldx + b * 256 + 4 * lane);
+            uint32_t p; float dd; int bs;
+            q8_K_block(v, lane, p, dd, bs);
+            *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + b * 256 + 4 * lane) = p;
+            if (lane == 0) d[(int64_t) r * nb + b] = dd;
+            if (bsum && (lane & 3) == 0) bsum[(int64_t) r * (K / 16) + b * 16 + lane / 4] = (int16_t) bs;
+        }
+    }
+}
+
+// standalone kernel (parity tests, and the MFMA path's first stage uses its own variant)
+template <int ACT>
+__global__ void __launch_bounds__(256) quantize_act_kernel(const float * __restrict__ x, int64_t ldx, int rows, int K, int act_mode,
+                                                           int8_t * q, float * d, int16_t * bsum, int rows_per_block) {
+    const int r0 = blockIdx.x * rows_per_block;
+    const int nr = min(rows_per_block, rows - r0);
+    if (nr <= 0) return;
+    quantize_rows<ACT>(x + (int64_t) r0 * ldx, ldx, nr, K, act_mode, q + (int64_t) r0 * K,
+                       d + (int64_t) r0 * (K / (ACT == T_Q8_0 ? 32 : 256)),
+                       bsum ? bsum + (int64_t) r0 * (K / 16) : nullptr, threadIdx.x, blockDim.x);
+}
+
+} // namespace qmm

@@ -1,0 +1,335 @@
+// qmm_api.hip — host side of the C-ABI declared in include/ggml_mi355x_qmm.h.
+// gfx950 only; there is no CPU path: every failure is reported, nothing is silently emulated.
+
+#include "qmm_host.h"
+
+#include "qmm_matvec.cuh"
+#include "qmm_mfma.cuh"
+#include "qmm_moe.cuh"
+
+using namespace qmm;
+
+namespace {
+
+bool type_ok(int t) { return t == T_Q4_0 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K; }
+int  blck(int t) { return (t == T_Q4_0 || t == T_Q8_0) ? 32 : 256; }
+int  tsize(int t) {
+    switch (t) {
+        case T_Q4_0: return 18; case T_Q8_0: return 34; case T_Q4_K: return 144; case T_Q5_K: return 176;
+        case T_Q6_K: return 210; default: return 0;
+    }
+}
+
+} // namespace
+
+template <int T>
+static int launch_dequant(hipStream_t st, const void * w, int64_t rb, int64_t rows, int64_t K, float * dst) {
+    const int64_t n = rows * (K / Traits<T>::UNIT_W);
+    if (n == 0) return QMM_OK;
+    hipLaunchKernelGGL((dequant_kernel<T>), dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st,
+                       (const uint8_t *) w, rb, rows, (int) K, dst);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+template <int T, int NTOK>
+static int launch_matvec_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K) {
+    const size_t lds = matvec_lds_bytes<T, NTOK>(K);
+    if (lds > 160 * 1024) return fail(QMM_EUNSUPPORTED, "matvec: %d tokens x K=%d needs %zu B of LDS", NTOK, K, lds);
+    auto kern = matvec_kernel<T, NTOK>;
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    const int total = g.row_end[g.n - 1];
+    // waves per block: 16 (one block per CU covers 16 rows); small problems use smaller blocks to spread over CUs
+    int nw = 16;
+    while (nw > 4 && (total + nw - 1) / nw < c->cus) nw >>= 1;
+    if (lds > 80 * 1024) nw = 16;
+    int blocks = (total + nw - 1) / nw;
+    const int cap = c->cus * (lds > 80 * 1024 ? 1 : 2);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * WAVE), lds, st, g, x, ldx, K, c->act_mode);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+template <int T>
+static int launch_matvec(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K, int N) {
+    switch (N) {
+        case 1: return launch_matvec_n<T, 1>(c, st, g, x, ldx, K);
+        case 2: return launch_matvec_n<T, 2>(c, st, g, x, ldx, K);
+        case 3: return launch_matvec_n<T, 3>(c, st, g, x, ldx, K);
+        case 4: return launch_matvec_n<T, 4>(c, st, g, x, ldx, K);
+        case 5: return launch_matvec_n<T, 5>(c, st, g, x, ldx, K);
+        case 6: return launch_matvec_n<T, 6>(c, st, g, x, ldx, K);
+        case 7: return launch_matvec_n<T, 7>(c, st, g, x, ldx, K);
+        case 8: return launch_matvec_n<T, 8>(c, st, g, x, ldx, K);
+        default: return fail(QMM_EINVAL, "matvec: N=%d", N);
+    }
+}
+
+static int matvec_any(qmm_ctx * c, hipStream_t st, int type, const MatvecGroup & g, const float * x, int64_t ldx, int K, int N) {
+    switch (type) {
+        case T_Q4_0: return launch_matvec<T_Q4_0>(c, st, g, x, ldx, K, N);
+        case T_Q8_0: return launch_matvec<T_Q8_0>(c, st, g, x, ldx, K, N);
+        case T_Q4_K: return launch_matvec<T_Q4_K>(c, st, g, x, ldx, K, N);
+        case T_Q5_K: return launch_matvec<T_Q5_K>(c, st, g, x, ldx, K, N);
+        default:     return launch_matvec<T_Q6_K>(c, st, g, x, ldx, K, N);
+    }
+}
+
+static int check_mm(int type, const void * w, int64_t rb, int64_t K, const float * x, int64_t ldx, const char * who) {
+    if (!type_ok(type)) return fail(QMM_EUNSUPPORTED, "%s: type %d not supported", who, type);
+    if (K <= 0 || K % blck(type)) return fail(QMM_EUNSUPPORTED, "%s: K=%lld must be a multiple of %d", who, (long long) K, blck(type));
+    if (rb < (int64_t) qmm_row_size(type, K)) return fail(QMM_EINVAL, "%s: weight row stride %lld < row size", who, (long long) rb);
+    if ((uintptr_t) x % 16 || ldx % 4 || ldx < K) return fail(QMM_EINVAL, "%s: src1 must be 16-byte aligned with ldx %% 4 == 0", who);
+    return QMM_OK;
+}
+
+extern "C" {
+
+int qmm_abi_version(void) { return 1; }
+
+const char * qmm_last_error(void) { return last_error().c_str(); }
+
+int qmm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+qmm_ctx * qmm_create(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        fail(QMM_ENODEV, "qmm_create: no HIP device %d (count %d)", device, n);
+        return nullptr;
+    }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) {
+        fail(QMM_ENODEV, "qmm_create: hipGetDeviceProperties failed");
+        return nullptr;
+    }
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        fail(QMM_ENODEV, "qmm_create: device %d is %s; this library is built for gfx950 only", device, p.gcnArchName);
+        return nullptr;
+    }
+    qmm_ctx * c = new qmm_ctx;
+    c->device = device;
+    c->cus = p.multiProcessorCount;
+    snprintf(c->name, sizeof(c->name), "%s", p.name);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **) &c->flag, 16) != hipSuccess || hipMemset(c->flag, 0, 16) != hipSuccess) {
+        fail(QMM_EHIP, "qmm_create: stream/flag setup failed");
+        delete c;
+        return nullptr;
+    }
+    const char * e = getenv("GGML_MI355X_ACT_MODE");
+    if (e) c->act_mode = atoi(e) ? QMM_ACT_X86 : QMM_ACT_REF;
+    e = getenv("GGML_MI355X_PREC");
+    if (e) c->prec = (!strcmp(e, "bf16") || !strcmp(e, "0")) ? QMM_PREC_BF16 : QMM_PREC_F16_Q8;
+    return c;
+}
+
+void qmm_destroy(qmm_ctx * c) {
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    (void) hipDeviceSynchronize();
+    if (c->ws) (void) hipFree(c->ws);
+    if (c->flag) (void) hipFree(c->flag);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int qmm_device(const qmm_ctx * c) { return c ? c->device : -1; }
+
+void * qmm_stream(const qmm_ctx * c) { return c ? (void *) c->stream : nullptr; }
+
+int qmm_device_info(const qmm_ctx * c, char * name, size_t name_len, size_t * mem_free, size_t * mem_total, int * cus) {
+    if (!c) return fail(QMM_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    if (name && name_len) snprintf(name, name_len, "%s", c->name);
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (mem_free) *mem_free = f;
+    if (mem_total) *mem_total = t;
+    if (cus) *cus = c->cus;
+    return QMM_OK;
+}
+
+int qmm_set_act_mode(qmm_ctx * c, int m) {
+    if (!c || (m != QMM_ACT_REF && m != QMM_ACT_X86)) return fail(QMM_EINVAL, "bad act mode");
+    c->act_mode = m;
+    return QMM_OK;
+}
+int qmm_set_precision(qmm_ctx * c, int p) {
+    if (!c || (p != QMM_PREC_BF16 && p != QMM_PREC_F16_Q8)) return fail(QMM_EINVAL, "bad precision");
+    c->prec = p;
+    return QMM_OK;
+}
+
+void * qmm_malloc(qmm_ctx * c, size_t bytes) {
+    if (!c) return nullptr;
+    void * p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        fail(QMM_ENOMEM, "hipMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+void qmm_free(qmm_ctx * c, void * p) {
+    if (!c || !p) return;
+    (void) hipSetDevice(c->device);
+    (void) hipFree(p);
+}
+int qmm_memcpy_h2d(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->s(st)));
+    HIP_TRY(hipStreamSynchronize(c->s(st)));
+    return QMM_OK;
+}
+int qmm_memcpy_d2h(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->s(st)));
+    HIP_TRY(hipStreamSynchronize(c->s(st)));
+    return QMM_OK;
+}
+int qmm_memcpy_d2d(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->s(st)));
+    return QMM_OK;
+}
+int qmm_memset(qmm_ctx * c, void * dst, int v, size_t n, void * st) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(dst, v, n, c->s(st)));
+    return QMM_OK;
+}
+int qmm_synchronize(qmm_ctx * c, void * st) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->s(st)));
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(c->flag, 0, sizeof(int)));
+        return fail(QMM_EINVAL, "MUL_MAT_ID: expert id out of range seen by the kernel");
+    }
+    return QMM_OK;
+}
+
+size_t qmm_row_size(int type, int64_t k) {
+    if (!type_ok(type) || k % blck(type)) return 0;
+    return (size_t) (k / blck(type)) * tsize(type);
+}
+
+// ------------------------------------------------------------------------------------------- dequantize
+
+int qmm_dequantize(qmm_ctx * c, int type, const void * w, int64_t rb, int64_t rows, int64_t K, float * dst, void * st) {
+    if (!c || !type_ok(type)) return fail(QMM_EINVAL, "qmm_dequantize: bad ctx/type %d", type);
+    if (K <= 0 || K % blck(type)) return fail(QMM_EINVAL, "qmm_dequantize: K=%lld", (long long) K);
+    if (rb < (int64_t) qmm_row_size(type, K)) return fail(QMM_EINVAL, "qmm_dequantize: row stride too small");
+    if ((uintptr_t) dst % 16) return fail(QMM_EINVAL, "qmm_dequantize: dst must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->s(st);
+    switch (type) {
+        case T_Q4_0: return launch_dequant<T_Q4_0>(s, w, rb, rows, K, dst);
+        case T_Q8_0: return launch_dequant<T_Q8_0>(s, w, rb, rows, K, dst);
+        case T_Q4_K: return launch_dequant<T_Q4_K>(s, w, rb, rows, K, dst);
+        case T_Q5_K: return launch_dequant<T_Q5_K>(s, w, rb, rows, K, dst);
+        default:     return launch_dequant<T_Q6_K>(s, w, rb, rows, K, dst);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- quantize_act
+
+int qmm_quantize_act(qmm_ctx * c, int vt, const float * x, int64_t rows, int64_t K, int64_t ldx,
+                     int8_t * q, float * d, int16_t * bs, void * st) {
+    if (!c || (vt != T_Q8_0 && vt != T_Q8_K)) return fail(QMM_EINVAL, "qmm_quantize_act: vec_dot_type %d", vt);
+    if (K <= 0 || K % (vt == T_Q8_0 ? 32 : 256) || ldx % 4 || (uintptr_t) x % 16 || (uintptr_t) q % 4)
+        return fail(QMM_EINVAL, "qmm_quantize_act: K/ldx/alignment");
+    if (rows == 0) return QMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int rpb = 4;
+    dim3 grid((unsigned) ((rows + rpb - 1) / rpb));
+    if (vt == T_Q8_0)
+        hipLaunchKernelGGL((quantize_act_kernel<T_Q8_0>), grid, dim3(256), 0, c->s(st), x, ldx, (int) rows, (int) K, c->act_mode, q, d, bs, rpb);
+    else
+        hipLaunchKernelGGL((quantize_act_kernel<T_Q8_K>), grid, dim3(256), 0, c->s(st), x, ldx, (int) rows, (int) K, c->act_mode, q, d, bs, rpb);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------- mat-vec
+
+int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, const float * x, int64_t N, int64_t ldx, void * stream) {
+    if (!c || !ws || nw <= 0) return fail(QMM_EINVAL, "qmm_mul_mat_group: bad arguments");
+    if (N <= 0) return QMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->s(stream);
+    for (int i = 0; i < nw; ++i) {
+        int rc = check_mm(ws[i].type, ws[i].w, ws[i].w_row_bytes, K, x, ldx, "qmm_mul_mat");
+        if (rc) return rc;
+        if (ws[i].M < 0 || ws[i].ldd < ws[i].M) return fail(QMM_EINVAL, "qmm_mul_mat: ldd < M");
+    }
+    if (N <= QMM_MATVEC_MAX_N) {
+        // one launch per run of same-type weights (they share the in-kernel activation quantization)
+        int i = 0;
+        while (i < nw) {
+            MatvecGroup g;
+            memset(&g, 0, sizeof(g));
+            int rows = 0, j = i;
+            while (j < nw && ws[j].type == ws[i].type && g.n < MV_MAX_GROUP) {
+                if (ws[j].M > 0) {
+                    g.w[g.n] = (const uint8_t *) ws[j].w;
+                    g.dst[g.n] = ws[j].dst;
+                    g.row_bytes[g.n] = ws[j].w_row_bytes;
+                    g.ldd[g.n] = ws[j].ldd;
+                    rows += (int) ws[j].M;
+                    g.row_end[g.n] = rows;
+                    g.n++;
+                }
+                ++j;
+            }
+            if (g.n > 0) {
+                // tokens that do not fit LDS together are processed in sub-batches
+                int n_at_once = (int) N;
+                while (n_at_once > 1 && ((size_t) n_at_once * K * 5 / 4 + 4096) > 150 * 1024) n_at_once = (n_at_once + 1) / 2;
+                for (int64_t n0 = 0; n0 < N; n0 += n_at_once) {
+                    const int nn = (int) ((N - n0) < n_at_once ? (N - n0) : n_at_once);
+                    MatvecGroup gg = g;
+                    for (int k = 0; k < gg.n; ++k) gg.dst[k] = g.dst[k] + n0 * g.ldd[k];
+                    int rc = matvec_any(c, st, ws[i].type, gg, x + n0 * ldx, ldx, (int) K, nn);
+                    if (rc) return rc;
+                }
+            }
+            i = j;
+        }
+        return QMM_OK;
+    }
+    for (int i = 0; i < nw; ++i) {
+        if (ws[i].M == 0) continue;
+        int rc = mfma_mul_mat(c, st, ws[i].type, ws[i].w, ws[i].w_row_bytes, K, ws[i].M, x, N, ldx, ws[i].dst, ws[i].ldd, i > 0);
+        if (rc) return rc;
+    }
+    return QMM_OK;
+}
+
+int qmm_mul_mat(qmm_ctx * c, int type, const void * w, int64_t rb, int64_t K, int64_t M,
+                const float * x, int64_t N, int64_t ldx, float * dst, int64_t ldd, void * stream) {
+    qmm_weight ws = { w, rb, M, dst, ldd, type };
+    return qmm_mul_mat_group(c, &ws, 1, K, x, N, ldx, stream);
+}
+
+int qmm_mul_mat_id(qmm_ctx * c, int type, const void * as, int64_t rb, int64_t expert_bytes,
+                   int64_t K, int64_t M, int64_t n_expert,
+                   const float * b, int64_t ne11, int64_t b_nb1, int64_t b_nb2,
+                   const int32_t * ids, int64_t n_used, int64_t n_tokens, int64_t ids_nb1,
+                   float * dst, int64_t d_nb1, int64_t d_nb2, void * stream) {
+    if (!c) return fail(QMM_EINVAL, "null ctx");
+    int rc = check_mm(type, as, rb, K, b, K, "qmm_mul_mat_id");
+    if (rc) return rc;
+    if (b_nb1 % 16 || b_nb2 % 16 || ids_nb1 % 4 || d_nb1 % 4 || d_nb2 % 4 || expert_bytes % 2 || (ne11 != 1 && ne11 != n_used))
+        return fail(QMM_EINVAL, "qmm_mul_mat_id: strides / ne11");
+    if (n_tokens <= 0 || n_used <= 0 || M <= 0) return QMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    return moe_mul_mat_id(c, c->s(stream), type, as, rb, expert_bytes, K, M, n_expert, b, ne11, b_nb1, b_nb2,
+                          ids, n_used, n_tokens, ids_nb1, dst, d_nb1, d_nb2);
+}
+
+} // extern "C"

@@ -1,0 +1,68 @@
+// qmm_host.h — host-side context and error plumbing shared by the launchers.
+#pragma once
+
+#include "../../include/ggml_mi355x_qmm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+struct qmm_ctx {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    int         cus = 0;
+    int         act_mode = QMM_ACT_REF;
+    int         prec = QMM_PREC_F16_Q8;
+    // workspace of the batched path (16-bit activations, row scales, MoE lists); grown on demand
+    void *      ws = nullptr;
+    size_t      ws_bytes = 0;
+    int *       flag = nullptr;      // device word set by kernels that meet an expert id out of range
+    char        name[128] = {0};
+
+    // `st` is used verbatim: NULL is HIP's default stream (what torch's default stream is), not ours
+    hipStream_t s(void * st) const { return (hipStream_t) st; }
+};
+
+namespace qmm {
+
+inline std::string & last_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+inline int fail(int code, const char * fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return ::qmm::fail(QMM_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// grows the context workspace; synchronizes the device when it has to reallocate
+inline int ensure_ws(qmm_ctx * c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return QMM_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->ws) HIP_TRY(hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+    const size_t gran = (size_t) 32 << 20;
+    const size_t want = (bytes + gran - 1) / gran * gran;
+    HIP_TRY(hipMalloc(&c->ws, want));
+    c->ws_bytes = want;
+    return QMM_OK;
+}
+
+} // namespace qmm

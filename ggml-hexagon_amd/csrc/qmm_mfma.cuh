@@ -1,0 +1,338 @@
+// qmm_mfma.cuh — batched (prefill) quantized mat-mul on the gfx950 matrix cores.
+//
+//   dst[n, m] = sum_k W[m, k] * x[n, k]        N > 8 tokens
+//
+// Two launches per MUL_MAT:
+//   1. prep_act_kernel  f32 activations -> 16-bit MFMA operand rows  Xh[Npad][Kp]  (+ one f32 scale per token)
+//        QMM_PREC_F16_Q8 : the row is quantized to Q8_0 / Q8_K exactly as the CPU backend does
+//                          (ggml-cpu.c:6807-6842), then each value q*d is stored as f16 relative to the
+//                          row's largest block scale (|value| <= 127, no f16 range problem); the GEMM
+//                          therefore multiplies the SAME quantized activations as ggml's vec_dot, and the
+//                          only difference left is f16 rounding of the operands (~2^-12 relative).
+//        QMM_PREC_BF16   : plain round-to-nearest bf16 of x (no Q8 emulation).
+//   2. mfma_kernel      each workgroup owns a BN-token x BM-row tile of dst.  Per K-step it
+//        - fetches one weight *unit* per thread straight from HBM (16-byte loads, qmm_device.cuh),
+//          unpacks it bit-exactly to f32 (Unit<T>::to_f32), rounds to f16/bf16 and stores it into the
+//          XOR-swizzled LDS tile Ws[BM][BK];
+//        - copies the matching Xh tile into Xs[BN][BK];
+//        - runs v_mfma_f32_32x32x16_{f16,bf16} with tokens on the MFMA row index and weight rows on
+//          the column (= lane) index, so that the epilogue writes 128 contiguous bytes of dst per
+//          half-wave.
+//      Global loads for K-step s+1 are issued before the MFMAs of step s (register prefetch).
+//
+// MoE (MUL_MAT_ID) reuses the kernel: blockIdx.z selects the expert, seg_start/seg_count (device
+// arrays) give the expert's slice of the expert-sorted token list, dst_off scatters the rows.
+#pragma once
+
+#include "qmm_act.cuh"
+#include "qmm_host.h"
+
+namespace qmm {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16   bf16x8 __attribute__((ext_vector_type(8)));
+typedef float    f32x16 __attribute__((ext_vector_type(16)));
+
+template <int T> struct MfmaBK { static constexpr int value = 64; };
+template <> struct MfmaBK<T_Q6_K> { static constexpr int value = 128; };
+
+// physical byte offset of 16-byte slot `s` of row `r` in a [rows][BK] 16-bit tile
+template <int BK> __device__ __forceinline__ int tile_off(int r, int s) {
+    if (BK == 64) return r * 128 + ((s ^ ((r >> 1) & 7)) << 4);
+    else          return r * 256 + ((s ^ (r & 15)) << 4);
+}
+
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+    const __half2 h = __floats2half2_rn(a, b);
+    return *reinterpret_cast<const uint32_t *>(&h);
+}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 v;
+    v[0] = (__bf16) a;
+    v[1] = (__bf16) b;
+    return *reinterpret_cast<const uint32_t *>(&v);
+}
+template <bool F16> __device__ __forceinline__ uint32_t pack16(float a, float b) { return F16 ? pack_f16(a, b) : pack_bf16(a, b); }
+
+// ------------------------------------------------------------------------------------------------
+// stage 1: activation rows -> MFMA operand rows.  One workgroup per output row.
+//   src row r: x + gather(r)   (gather == nullptr: r*ldx; MoE: element offset of the pair's src1 row)
+//   out row r: xh + r*Kp   (16-bit), scale[r]
+template <int ACT, bool F16Q8>
+__global__ void __launch_bounds__(256)
+prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t * __restrict__ gather,
+                const int * __restrict__ n_rows_dev, const int n_rows, const int K, const int Kp, const int act_mode,
+                uint16_t * __restrict__ xh, float * __restrict__ scale) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int live_rows = n_rows_dev ? *n_rows_dev : n_rows;
+    uint16_t * out = xh + (int64_t) r * Kp;
+    if (r >= live_rows) {                                   // padding rows: zeros
+        for (int k = tid * 8; k < Kp; k += 256 * 8) *reinterpret_cast<uint4 *>(out + k) = make_uint4(0, 0, 0, 0);
+        if (tid == 0) scale[r] = 0.0f;
+        return;
+    }
+    const float * src = x + (gather ? gather[r] : (int64_t) r * ldx);
+    if (!F16Q8) {
+        for (int k = tid * 8; k < Kp; k += 256 * 8) {
+            uint4 o = make_uint4(0, 0, 0, 0);
+            if (k < K) {
+                const float4 a = *reinterpret_cast<const float4 *>(src + k);
+                const float4 b = *reinterpret_cast<const float4 *>(src + k + 4);
+                o = make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
+            }
+            *reinterpret_cast<uint4 *>(out + k) = o;
+        }
+        if (tid == 0) scale[r] = 1.0f;
+        return;
+    }
+    constexpr int QB = ACT == T_Q8_0 ? 32 : 256;
+    int8_t * aq = reinterpret_cast<int8_t *>(smem);
+    float *  ad = reinterpret_cast<float *>(smem + K);
+    float *  red = ad + K / QB;                              // 4 floats for the block max
+    quantize_rows<ACT>(src, 0, 1, K, act_mode, aq, ad, nullptr, tid, 256);
+    __syncthreads();
+    float mx = 0.0f;
+    for (int b = tid; b < K / QB; b += 256) mx = fmaxf(mx, fabsf(ad[b]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float inv = mx > 0.0f ? 1.0f / mx : 0.0f;
+    for (int k = tid * 8; k < Kp; k += 256 * 8) {
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (k < K) {
+            const float t = ad[k / QB] * inv;                // |t| <= 1
+            const int2 qq = *reinterpret_cast<const int2 *>(aq + k);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i]     = (float) (int8_t) ((qq.x >> (8 * i)) & 0xff) * t;
+                v[4 + i] = (float) (int8_t) ((qq.y >> (8 * i)) & 0xff) * t;
+            }
+            o = make_uint4(pack_f16(v[0], v[1]), pack_f16(v[2], v[3]), pack_f16(v[4], v[5]), pack_f16(v[6], v[7]));
+        }
+        *reinterpret_cast<uint4 *>(out + k) = o;
+    }
+    if (tid == 0) scale[r] = mx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2
+template <int T, int BM, bool F16>
+__global__ void __launch_bounds__(256)
+mfma_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64_t expert_bytes, const int M, const int K,
+            const uint16_t * __restrict__ Xh, const int Kp, const float * __restrict__ scale,
+            const int * __restrict__ seg_start, const int * __restrict__ seg_count, const int N,
+            float * __restrict__ dst, const int64_t ldd, const int64_t * __restrict__ dst_off) {
+    constexpr int BN = 128;
+    constexpr int BK = MfmaBK<T>::value;
+    constexpr int ROWB = BK * 2;
+    constexpr int SLOTS = BK / 8;                            // 16-byte slots per tile row
+    constexpr int UPS = BK / Traits<T>::UNIT_W;              // weight units per row per K-step (= 2)
+    constexpr int W_UNITS = BM * UPS;                        // units per K-step (128 or 256)
+    constexpr int X_CHUNKS = BN * SLOTS / 256;               // 16-byte chunks per thread per K-step
+    constexpr int RT = BM / 64;                              // 32-row MFMA tiles per wave along the weight rows
+    static_assert(UPS == 2, "unit/K-step geometry");
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(BM + BN) * ROWB];
+    uint8_t * Ws = lds;
+    uint8_t * Xs = lds + BM * ROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg0 = seg_start ? seg_start[blockIdx.z] : 0;
+    const int segn = seg_count ? seg_count[blockIdx.z] : N;
+    const int tok0 = blockIdx.y * BN;                        // within the segment
+    if (tok0 >= segn) return;
+    const int row0 = blockIdx.x * BM;
+    const uint8_t * Wz = W + (int64_t) blockIdx.z * expert_bytes;
+
+    // this thread's weight unit: row (tid>>1), half (tid&1); rows past M re-read row M-1 (never stored)
+    const bool has_w = tid < W_UNITS;
+    const int  wr = tid >> 1;
+    const uint8_t * wrow = Wz + (int64_t) min(row0 + wr, M - 1) * row_bytes;
+    const int units_per_row = K / Traits<T>::UNIT_W;
+
+    // this thread's activation chunks: chunk c = tid + 256*i -> row c / SLOTS, slot c % SLOTS
+    const uint16_t * xbase = Xh + (int64_t) (seg0 + tok0) * Kp;
+
+    const int wave_t = (wave & 1) * 64;                      // token offset of the wave inside the tile
+    const int wave_r = (wave >> 1) * (BM / 2);               // weight-row offset
+
+    f32x16 acc[2][RT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    Unit<T> wu;
+    uint4   xc[X_CHUNKS];
+    const int nk = Kp / BK;
+
+    auto fetch = [&](int ks) {
+        const int u = ks * UPS + (tid & 1);
+        if (has_w && u < units_per_row) wu.load(wrow, u);
+#pragma unroll
+        for (int i = 0; i < X_CHUNKS; ++i) {
+            const int c = tid + 256 * i;
+            xc[i] = *reinterpret_cast<const uint4 *>(xbase + (int64_t) (c / SLOTS) * Kp + ks * BK + (c % SLOTS) * 8);
+        }
+    };
+    auto stash = [&](int ks) {
+        const int u = ks * UPS + (tid & 1);
+        if (has_w) {
+            float v[Traits<T>::UNIT_W];
+            if (u < units_per_row) {
+                wu.to_f32(u, v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < Traits<T>::UNIT_W; ++e) v[e] = 0.0f;
+            }
+#pragma unroll
+            for (int rr = 0; rr < Unit<T>::RUNS; ++rr) {
+                const int kk = Unit<T>::k_run(ks * UPS + (tid & 1), rr) - ks * BK;      // offset inside the K-step window
+#pragma unroll
+                for (int e = 0; e < Unit<T>::RUN_LEN; e += 8) {
+                    const float * p = v + rr * Unit<T>::RUN_LEN + e;
+                    const uint4 o = make_uint4(pack16<F16>(p[0], p[1]), pack16<F16>(p[2], p[3]),
+                                               pack16<F16>(p[4], p[5]), pack16<F16>(p[6], p[7]));
+                    *reinterpret_cast<uint4 *>(Ws + tile_off<BK>(wr, (kk + e) >> 3)) = o;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < X_CHUNKS; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<uint4 *>(Xs + tile_off<BK>(c / SLOTS, c % SLOTS)) = xc[i];
+        }
+    };
+
+    fetch(0);
+    for (int ks = 0; ks < nk; ++ks) {
+        stash(ks);
+        __syncthreads();
+        if (ks + 1 < nk) fetch(ks + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int slot = kk * 2 + (lane >> 5);
+            uint4 a[2], b[RT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const uint4 *>(Xs + tile_off<BK>(wave_t + 32 * i + (lane & 31), slot));
+#pragma unroll
+            for (int j = 0; j < RT; ++j) b[j] = *reinterpret_cast<const uint4 *>(Ws + tile_off<BK>(wave_r + 32 * j + (lane & 31), slot));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < RT; ++j) {
+                    if (F16)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a[i]),
+                                                                          *reinterpret_cast<const f16x8 *>(&b[j]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a[i]),
+                                                                           *reinterpret_cast<const bf16x8 *>(&b[j]), acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: D[i = token][j = weight row]; lane -> weight row, registers -> tokens
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int t = tok0 + wave_t + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (t < segn) {
+                const float sc = scale[seg0 + t];
+                float * drow = dst + (dst_off ? dst_off[seg0 + t] : (int64_t) t * ldd);
+#pragma unroll
+                for (int j = 0; j < RT; ++j) {
+                    const int m = row0 + wave_r + 32 * j + (lane & 31);
+                    if (m < M) drow[m] = acc[i][j][e] * sc;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+
+inline int mfma_kpad(int64_t K) { return (int) ((K + 127) / 128 * 128); }
+inline int mfma_npad(int64_t N) { return (int) ((N + 127) / 128 * 128); }
+
+struct MfmaOperand {            // a prepared activation matrix in the workspace
+    const uint16_t * xh;
+    const float *    scale;
+    int              Kp;
+};
+
+template <int ACT>
+inline int launch_prep(qmm_ctx * c, hipStream_t st, const float * x, int64_t ldx, const int64_t * gather, const int * n_dev,
+                       int n_rows, int n_pad, int K, int Kp, uint16_t * xh, float * scale) {
+    const size_t lds = (size_t) K + (size_t) (K / 32) * 4 + 64;
+    if (c->prec == QMM_PREC_F16_Q8)
+        hipLaunchKernelGGL((prep_act_kernel<ACT, true>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
+                           c->act_mode, xh, scale);
+    else
+        hipLaunchKernelGGL((prep_act_kernel<ACT, false>), dim3(n_pad), dim3(256), 0, st, x, ldx, gather, n_dev, n_rows, K, Kp,
+                           c->act_mode, xh, scale);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+template <int T>
+inline int launch_mfma(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
+                       const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
+                       float * dst, int64_t ldd, const int64_t * dst_off) {
+    const bool f16 = c->prec == QMM_PREC_F16_Q8;
+    // 64-row tiles when 128-row tiles would leave CUs idle
+    const bool small = (int64_t) ((M + 127) / 128) * n_tiles_y * n_expert < c->cus;
+    const dim3 block(256);
+#define QMM_LAUNCH(BMv, F16v)                                                                                                      \
+    hipLaunchKernelGGL((mfma_kernel<T, BMv, F16v>), dim3((M + BMv - 1) / BMv, n_tiles_y, n_expert), block, 0, st, (const uint8_t *) W, \
+                       rb, eb, M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off)
+    if (small) { if (f16) QMM_LAUNCH(64, true); else QMM_LAUNCH(64, false); }
+    else       { if (f16) QMM_LAUNCH(128, true); else QMM_LAUNCH(128, false); }
+#undef QMM_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+inline int launch_mfma_any(qmm_ctx * c, hipStream_t st, int type, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
+                           const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
+                           float * dst, int64_t ldd, const int64_t * dst_off) {
+    switch (type) {
+        case T_Q4_0: return launch_mfma<T_Q4_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
+        case T_Q8_0: return launch_mfma<T_Q8_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
+        case T_Q4_K: return launch_mfma<T_Q4_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
+        case T_Q5_K: return launch_mfma<T_Q5_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
+        default:     return launch_mfma<T_Q6_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
+    }
+}
+
+// plain MUL_MAT, N > 8.  `reuse_prep`: the previous call of a group already prepared the same src1.
+inline int mfma_mul_mat(qmm_ctx * c, hipStream_t st, int type, const void * W, int64_t rb, int64_t K, int64_t M,
+                        const float * x, int64_t N, int64_t ldx, float * dst, int64_t ldd, bool reuse_prep) {
+    const int Kp = mfma_kpad(K), Np = mfma_npad(N);
+    const size_t xh_bytes = (size_t) Np * Kp * 2;
+    const size_t need = xh_bytes + (size_t) Np * 4 + 256;
+    int rc = ensure_ws(c, need);
+    if (rc) return rc;
+    uint16_t * xh = (uint16_t *) c->ws;
+    float * scale = (float *) ((uint8_t *) c->ws + xh_bytes);
+    const bool q8_0 = (type == T_Q4_0 || type == T_Q8_0);
+    if (!reuse_prep || c->prec == QMM_PREC_F16_Q8) {
+        // (with Q8 emulation the operand depends on the weight type's activation format, so only same-format
+        //  neighbours could share it; keep it simple and prepare per call)
+        rc = q8_0 ? launch_prep<T_Q8_0>(c, st, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, xh, scale)
+                  : launch_prep<T_Q8_K>(c, st, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, xh, scale);
+        if (rc) return rc;
+    }
+    MfmaOperand op = { xh, scale, Kp };
+    return launch_mfma_any(c, st, type, W, rb, 0, 1, (int) M, (int) K, op, nullptr, nullptr, (int) N, Np / 128, dst, ldd, nullptr);
+}
+
+} // namespace qmm

@@ -1,0 +1,138 @@
+/*
+ * ggml_mi355x_qmm.h — C-ABI of the MI355X (gfx950) quantized MUL_MAT / MUL_MAT_ID kernels.
+ *
+ * This is the device-side boundary of the hot path: the place where zhouwg/ggml-hexagon crosses from
+ * its host backend into the cDSP kernel library.  Each entry point names the reference interface it
+ * replaces; paths are relative to the reference tree (ggml/src/ggml-hexagon/...).
+ *
+ *   reference                                                     here
+ *   ------------------------------------------------------------  -----------------------------
+ *   ggmlop_dsp_open / _close   (kernels/ggmlop_ap_skel.h:246-262,  qmm_create / qmm_destroy
+ *     ggml-hexagon.cpp:4821-4973 ggmlhexagon_init_dsp)
+ *   ggmlop_dsp_setclocks       (kernels/ggml-dsp.c:900-946)        — none needed on MI355X —
+ *   rpcmem pool                (ggml-hexagon.cpp:4698-4747)        qmm_malloc / qmm_free / qmm_memcpy_*
+ *   ggmlop_dsp_mulmat(h, src0, src1, dst)                          qmm_mul_mat / qmm_mul_mat_group
+ *     (kernels/ggmlop_ap_skel.h:271, kernels/ggml-dsp.c:1192-1351;
+ *      `dsptensor` wire struct kernels/ggmlop_ap_skel.h:234-244)
+ *   (MUL_MAT_ID: absent from the reference, ggml-hexagon.cpp:514;  qmm_mul_mat_id
+ *    semantics = ggml-cpu.c:6941-7197)
+ *   from_float(src1 rows) inside ggmlop_dsp_mulmat                 qmm_quantize_act (exposed for parity tests;
+ *     (kernels/ggml-dsp.c:1262-1285)                                 the hot kernels do it in LDS themselves)
+ *   dequantize_row_q6_K etc.   (kernels/ggml-dsp.c:696-725)        qmm_dequantize
+ *
+ * Conventions
+ *   - every `const void *` / `float *` data argument is a DEVICE pointer on the context's GPU;
+ *   - `stream` is a hipStream_t passed as void* and used verbatim (NULL = HIP's default stream);
+ *     qmm_stream() returns a non-blocking stream owned by the context for callers that want one.
+ *     Calls are asynchronous on that stream; nothing synchronizes except qmm_synchronize / qmm_memcpy_h2d/_d2h;
+ *   - `type` is ggml's enum ggml_type value: Q4_0=2, Q8_0=8, Q4_K=12, Q5_K=13, Q6_K=14;
+ *   - weights are in GGUF wire layout: rows of blocks, `w_row_bytes` apart (>= K/blck*type_size);
+ *   - returns 0 on success, a negative QMM_E* code otherwise (qmm_last_error() has the text).
+ *     Nothing falls back to the CPU.
+ */
+#ifndef GGML_MI355X_QMM_H
+#define GGML_MI355X_QMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#  define QMM_API __declspec(dllexport)
+#else
+#  define QMM_API __attribute__((visibility("default")))
+#endif
+
+typedef struct qmm_ctx qmm_ctx;
+
+enum {
+    QMM_OK = 0,
+    QMM_EINVAL = -1,      /* bad shape / alignment / type */
+    QMM_ENODEV = -2,      /* no gfx950 device / HIP runtime failure at init */
+    QMM_EHIP = -3,        /* a HIP call failed */
+    QMM_ENOMEM = -4,
+    QMM_EUNSUPPORTED = -5
+};
+
+/* activation rounding variant of the Q8_0 quantizer (see oracle/qmm_oracle.h) */
+enum { QMM_ACT_REF = 0, QMM_ACT_X86 = 1 };
+
+/* numerics of the batched (N > QMM_MATVEC_MAX_N) kernel */
+enum {
+    QMM_PREC_BF16 = 0,     /* dequantized weights and activations rounded to bf16, f32 MFMA accumulate   */
+    QMM_PREC_F16_Q8 = 1    /* activations Q8-quantized as the CPU backend does, then f16 MFMA (default)  */
+};
+#define QMM_MATVEC_MAX_N 8
+
+QMM_API int          qmm_abi_version(void);
+QMM_API const char * qmm_last_error(void);
+QMM_API int          qmm_device_count(void);
+
+QMM_API qmm_ctx *    qmm_create(int device);
+QMM_API void         qmm_destroy(qmm_ctx * ctx);
+QMM_API int          qmm_device(const qmm_ctx * ctx);
+QMM_API void *       qmm_stream(const qmm_ctx * ctx);
+QMM_API int          qmm_device_info(const qmm_ctx * ctx, char * name, size_t name_len,
+                                     size_t * mem_free, size_t * mem_total, int * compute_units);
+QMM_API int          qmm_set_act_mode(qmm_ctx * ctx, int act_mode);
+QMM_API int          qmm_set_precision(qmm_ctx * ctx, int prec);
+
+QMM_API void *       qmm_malloc(qmm_ctx * ctx, size_t bytes);
+QMM_API void         qmm_free(qmm_ctx * ctx, void * dptr);
+QMM_API int          qmm_memcpy_h2d(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
+QMM_API int          qmm_memcpy_d2h(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
+QMM_API int          qmm_memcpy_d2d(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
+QMM_API int          qmm_memset(qmm_ctx * ctx, void * dst, int value, size_t bytes, void * stream);
+QMM_API int          qmm_synchronize(qmm_ctx * ctx, void * stream);
+
+QMM_API size_t       qmm_row_size(int type, int64_t k);
+
+/* dst f32 [rows, K] (contiguous) = bit-exact unpack of `rows` weight rows */
+QMM_API int qmm_dequantize(qmm_ctx * ctx, int type, const void * w, int64_t w_row_bytes,
+                           int64_t rows, int64_t K, float * dst, void * stream);
+
+/* Activation quantizer in the device layout the kernels use (structure of arrays):
+ *   q  int8  [rows, K]
+ *   d  f32   [rows, K/32]   for Q8_0 (the fp16-rounded scale, widened)   | [rows, K/256] for Q8_K
+ *   bs int16 [rows, K/16]   Q8_K only (may be NULL)
+ * `vec_dot_type` is 8 (Q8_0) or 15 (Q8_K).  x rows are ldx floats apart. */
+QMM_API int qmm_quantize_act(qmm_ctx * ctx, int vec_dot_type, const float * x, int64_t rows, int64_t K,
+                             int64_t ldx, int8_t * q, float * d, int16_t * bs, void * stream);
+
+/* dst[n*ldd + m] = sum_k W[m,k] * x[n*ldx + k]    m < M, n < N   (GGML_OP_MUL_MAT, src1/dst f32) */
+QMM_API int qmm_mul_mat(qmm_ctx * ctx, int type, const void * w, int64_t w_row_bytes, int64_t K, int64_t M,
+                        const float * x, int64_t N, int64_t ldx, float * dst, int64_t ldd, void * stream);
+
+/* several MUL_MATs that share src1 (wq/wk/wv, ffn gate/up) in one launch when N <= QMM_MATVEC_MAX_N */
+typedef struct qmm_weight {
+    const void * w;
+    int64_t      w_row_bytes;
+    int64_t      M;
+    float *      dst;
+    int64_t      ldd;
+    int          type;
+} qmm_weight;
+
+QMM_API int qmm_mul_mat_group(qmm_ctx * ctx, const qmm_weight * ws, int n_weights, int64_t K,
+                              const float * x, int64_t N, int64_t ldx, void * stream);
+
+/* GGML_OP_MUL_MAT_ID.
+ *   as   [K, M, n_expert]  experts `expert_bytes` apart
+ *   b    f32 [K, ne11, n_tokens]   element (k, i11, t) at b[t*b_nb2/4 + i11*b_nb1/4 + k]   (ne11 = n_used or 1)
+ *   ids  int32 [n_used, n_tokens]  DEVICE pointer, rows `ids_nb1` bytes apart (strided views allowed)
+ *   dst  f32 [M, n_used, n_tokens] element (m, s, t) at dst[t*d_nb2/4 + s*d_nb1/4 + m]
+ * An id outside [0, n_expert) leaves its dst row untouched and makes the call return QMM_EINVAL
+ * at the next qmm_synchronize (the CPU backend asserts, ggml-cpu.c:7115). */
+QMM_API int qmm_mul_mat_id(qmm_ctx * ctx, int type, const void * as, int64_t w_row_bytes, int64_t expert_bytes,
+                           int64_t K, int64_t M, int64_t n_expert,
+                           const float * b, int64_t ne11, int64_t b_nb1, int64_t b_nb2,
+                           const int32_t * ids, int64_t n_used, int64_t n_tokens, int64_t ids_nb1,
+                           float * dst, int64_t d_nb1, int64_t d_nb2, void * stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,305 @@
+"""GPU parity tests proper: every call goes through the C-ABI (include/ggml_mi355x_qmm.h) into the HIP
+kernels and is checked against the CPU oracle / the golden vectors of the real reference.
+
+Bars (SURVEY.md §8a "parity modes"):
+  * block unpack and activation quantization: BIT-EXACT;
+  * mat-vec (N <= 8, Q8-exact mode): only f32 summation order differs from the CPU backend -> max |err| / rms <= 2e-5
+    (north-star tolerance: 1e-3 rel on the f32 accumulator);
+  * MFMA path, QMM_PREC_F16_Q8 (default): same quantized activations as the CPU, f16 operand rounding only
+    -> rel-L2 <= 1e-3;  QMM_PREC_BF16: the reference's own bar NMSE <= 5e-4 (tests/test-backend-ops.cpp:1982-1984).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle.pyoracle import ACT_REF, ACT_X86, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, Q8_K, TYPE_NAMES  # noqa: E402
+
+ALL = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K)
+IDS = [TYPE_NAMES[t] for t in ALL]
+
+
+@pytest.fixture(scope="module")
+def qmm():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ggml_hexagon_amd.capi import Qmm
+    q = Qmm(0)          # raises if the HIP library is missing or the device is not gfx950: no fallback
+    yield q
+    q.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel_rms(got, want):
+    want = want.astype(np.float64)
+    return float(np.max(np.abs(got - want)) / max(np.sqrt(np.mean(want ** 2)), 1e-30))
+
+
+def rel_l2(got, want):
+    want = want.astype(np.float64)
+    return float(np.sqrt(np.sum((got - want) ** 2) / max(np.sum(want ** 2), 1e-30)))
+
+
+def nmse(got, want):
+    want = want.astype(np.float64)
+    return float(np.sum((got - want) ** 2) / max(np.sum(want ** 2), 1e-30))
+
+
+def weights(ref_or_none, t, m, k, seed):
+    """realistic weights when the real quantizer is available (oracle/_ref), synthetic valid blocks otherwise"""
+    import ggml_hexagon_amd.synth as synth
+    if ref_or_none is not None:
+        rng = np.random.default_rng(seed)
+        return ref_or_none.quantize_weights(t, rng.uniform(-1, 1, (m, k)).astype(np.float32))
+    return synth.synth_weights(t, m, k, seed=seed, sigma=0.3)
+
+
+@pytest.fixture(scope="module")
+def maybe_ref():
+    from oracle.pyoracle import RefGgml, ref_available
+    return RefGgml("avx2") if ref_available() else None
+
+
+# ----------------------------------------------------------------------------- bit-exact stages
+
+def test_dequant_golden_bit_exact(qmm, golden):
+    t, k = int(golden["type"]), int(golden["K"])
+    got = qmm.dequantize(t, dev(golden["w"]), k).cpu().numpy().view(np.uint32)
+    want = golden["deq_bits"]
+    nan = np.isnan(got.view(np.float32)) & np.isnan(want.view(np.float32))
+    assert ((got == want) | nan).all()
+
+
+@pytest.mark.parametrize("t", ALL, ids=IDS)
+def test_dequant_random_blocks_bit_exact(qmm, oracle, t):
+    import ggml_hexagon_amd.synth as synth
+    k = 2048 if t in (Q4_0, Q8_0) else 4096
+    w = synth.synth_weights(t, 37, k, seed=11)
+    got = qmm.dequantize(t, dev(w), k).cpu().numpy()
+    want = oracle.dequantize(t, w, k)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", [ACT_REF, ACT_X86])
+def test_activation_quantizer_bit_exact(qmm, oracle, golden, mode):
+    t = int(golden["type"])
+    vt = Q8_0 if t in (Q4_0, Q8_0) else Q8_K
+    rng = np.random.default_rng(3)
+    x = np.concatenate([golden["act"], rng.standard_normal((21, 512)).astype(np.float32) * 5])
+    qmm.set_act_mode(mode)
+    q, d, bs = qmm.quantize_act(vt, dev(x))
+    qmm.set_act_mode(ACT_REF)
+    wire = oracle.quantize_act(t, x, mode)                       # ggml wire blocks
+    rows = x.shape[0]
+    if vt == Q8_0:
+        blk = wire.reshape(rows, -1, 34)
+        want_d = blk[:, :, :2].copy().view(np.float16).astype(np.float32).reshape(rows, -1)
+        want_q = blk[:, :, 2:].copy().view(np.int8).reshape(rows, -1)
+    else:
+        blk = wire.reshape(rows, -1, 292)
+        want_d = blk[:, :, :4].copy().view(np.float32).reshape(rows, -1)
+        want_q = blk[:, :, 4:260].copy().view(np.int8).reshape(rows, -1)
+        want_bs = blk[:, :, 260:].copy().view(np.int16).reshape(rows, -1)
+        assert np.array_equal(bs.cpu().numpy(), want_bs)
+    assert np.array_equal(q.cpu().numpy(), want_q)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), want_d.view(np.uint32))
+
+
+def test_q8_K_double_rounding_ties_bit_exact(qmm, oracle):
+    """regression: hipcc's default -ffp-contract=fast fused iscale*x into the magic add of nearest_int"""
+    from helpers import q8_K_tie_rows
+    x = q8_K_tie_rows(3, 512, seed=4)
+    q, d, bs = qmm.quantize_act(Q8_K, dev(x))
+    blk = oracle.quantize_act(Q4_K, x).reshape(3, -1, 292)
+    assert np.array_equal(q.cpu().numpy(), blk[:, :, 4:260].copy().view(np.int8).reshape(3, -1))
+    assert np.array_equal(bs.cpu().numpy(), blk[:, :, 260:].copy().view(np.int16).reshape(3, -1))
+    # and through the fused in-kernel quantizer of the mat-vec path
+    import ggml_hexagon_amd.synth as synth
+    w = synth.synth_weights(Q6_K, 64, 512, seed=1, sigma=0.2)
+    got = qmm.mul_mat(Q6_K, dev(w), 512, dev(x)).cpu().numpy()
+    assert rel_rms(got, oracle.mul_mat(Q6_K, w, 512, x, ACT_REF)) < 2e-5
+
+
+# ----------------------------------------------------------------------------- mat-vec (N <= 8)
+
+@pytest.mark.parametrize("n", [1, 5])
+def test_matvec_golden(qmm, golden, n):
+    t, k = int(golden["type"]), int(golden["K"])
+    qmm.set_act_mode(ACT_X86)                                    # the golden graph ran the AVX2 quantizer
+    got = qmm.mul_mat(t, dev(golden["w"][:-1]), k, dev(golden["act"][:n])).cpu().numpy()
+    qmm.set_act_mode(ACT_REF)
+    assert rel_rms(got, golden[f"dst_n{n}"]) < 2e-5
+
+
+@pytest.mark.parametrize("t", ALL, ids=IDS)
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 8])
+def test_matvec_vs_oracle(qmm, oracle, maybe_ref, t, n):
+    k, m = 4096, 333
+    w = weights(maybe_ref, t, m, k, seed=t)
+    x = np.random.default_rng(n).uniform(-1, 1, (n, k)).astype(np.float32)
+    got = qmm.mul_mat(t, dev(w), k, dev(x)).cpu().numpy()
+    want = oracle.mul_mat(t, w, k, x, ACT_REF)
+    assert rel_rms(got, want) < 2e-5
+
+
+@pytest.mark.parametrize("t", ALL, ids=IDS)
+def test_matvec_small_and_ragged_shapes(qmm, oracle, t):
+    """test-backend-ops shapes: m=16,k=256 (tests/test-backend-ops.cpp:4132-4136); k = one block; m = 1"""
+    import ggml_hexagon_amd.synth as synth
+    for (m, k, n) in ((16, 256, 1), (16, 256, 8), (1, 256, 3), (5, 512 if t in (Q4_0, Q8_0) else 768, 2)):
+        w = synth.synth_weights(t, m, k, seed=m + k, sigma=0.2)
+        x = np.random.default_rng(k).uniform(-1, 1, (n, k)).astype(np.float32)
+        got = qmm.mul_mat(t, dev(w), k, dev(x)).cpu().numpy()
+        assert rel_rms(got, oracle.mul_mat(t, w, k, x, ACT_REF)) < 2e-5
+    if t in (Q4_0, Q8_0):                                       # k = blck (32)
+        w = synth.synth_weights(t, 7, 32, seed=1, sigma=0.2)
+        x = np.random.default_rng(0).uniform(-1, 1, (2, 32)).astype(np.float32)
+        got = qmm.mul_mat(t, dev(w), 32, dev(x)).cpu().numpy()
+        assert rel_rms(got, oracle.mul_mat(t, w, 32, x, ACT_REF)) < 2e-5
+
+
+def test_matvec_zero_activations_and_strided_dst(qmm, oracle):
+    import ggml_hexagon_amd.synth as synth
+    k, m = 1024, 40
+    w = synth.synth_weights(Q4_K, m, k, seed=2)
+    x = np.zeros((2, k), np.float32)
+    x[1, 300:] = np.random.default_rng(0).uniform(-1, 1, k - 300)
+    out = torch.full((2, m + 24), 7.0, device="cuda")            # ldd > M: the padding must stay untouched
+    qmm.mul_mat(Q4_K, dev(w), k, dev(x), out=out[:, :m])
+    o = out.cpu().numpy()
+    assert (o[:, m:] == 7.0).all() and (o[0, :m] == 0).all()
+    assert rel_rms(o[1:, :m], oracle.mul_mat(Q4_K, w, k, x, ACT_REF)[1:]) < 2e-5
+
+
+def test_group_launch_matches_single(qmm, maybe_ref):
+    k = 4096
+    ws = [(Q4_K, dev(weights(maybe_ref, Q4_K, 512, k, 1))), (Q4_K, dev(weights(maybe_ref, Q4_K, 128, k, 2))),
+          (Q6_K, dev(weights(maybe_ref, Q6_K, 128, k, 3)))]
+    for n in (1, 4, 64):
+        x = dev(np.random.default_rng(n).uniform(-1, 1, (n, k)).astype(np.float32))
+        outs = [torch.empty((n, w.shape[0]), device="cuda") for _, w in ws]
+        qmm.mul_mat_group(ws, k, x, outs)
+        for (t, w), o in zip(ws, outs):
+            assert torch.equal(o, qmm.mul_mat(t, w, k, x))
+
+
+# ----------------------------------------------------------------------------- MFMA path (N > 8)
+
+@pytest.mark.parametrize("t", ALL, ids=IDS)
+@pytest.mark.parametrize("n", [9, 32, 129, 512])
+def test_mfma_f16q8_vs_oracle(qmm, oracle, maybe_ref, t, n):
+    k, m = 2048, 200
+    w = weights(maybe_ref, t, m, k, seed=20 + t)
+    x = np.random.default_rng(n).uniform(-1, 1, (n, k)).astype(np.float32)
+    got = qmm.mul_mat(t, dev(w), k, dev(x)).cpu().numpy()
+    want = oracle.mul_mat(t, w, k, x, ACT_REF)
+    assert rel_l2(got, want) < 1e-3, rel_l2(got, want)
+
+
+@pytest.mark.parametrize("t", ALL, ids=IDS)
+def test_mfma_bf16_nmse(qmm, oracle, maybe_ref, t):
+    from ggml_hexagon_amd.capi import PREC_BF16, PREC_F16_Q8
+    k, m, n = 2048, 200, 64
+    w = weights(maybe_ref, t, m, k, seed=40 + t)
+    x = np.random.default_rng(1).uniform(-1, 1, (n, k)).astype(np.float32)
+    qmm.set_precision(PREC_BF16)
+    got = qmm.mul_mat(t, dev(w), k, dev(x)).cpu().numpy()
+    qmm.set_precision(PREC_F16_Q8)
+    assert nmse(got, oracle.mul_mat(t, w, k, x, ACT_REF)) < 5e-4
+
+
+@pytest.mark.parametrize("t", (Q4_0, Q4_K), ids=["q4_0", "q4_K"])
+def test_mfma_ragged(qmm, oracle, t):
+    import ggml_hexagon_amd.synth as synth
+    for (m, k, n) in ((16, 256, 9), (512, 256, 32), (77, 1024, 130), (130, 512, 257)):
+        w = synth.synth_weights(t, m, k, seed=m, sigma=0.2)
+        x = np.random.default_rng(n).uniform(-1, 1, (n, k)).astype(np.float32)
+        got = qmm.mul_mat(t, dev(w), k, dev(x)).cpu().numpy()
+        assert rel_l2(got, oracle.mul_mat(t, w, k, x, ACT_REF)) < 1e-3
+    if t == Q4_0:
+        w = synth.synth_weights(t, 20, 32, seed=3, sigma=0.2)    # k = blck, padded K-step
+        x = np.random.default_rng(5).uniform(-1, 1, (40, 32)).astype(np.float32)
+        got = qmm.mul_mat(t, dev(w), 32, dev(x)).cpu().numpy()
+        assert rel_l2(got, oracle.mul_mat(t, w, 32, x, ACT_REF)) < 1e-3
+
+
+# ----------------------------------------------------------------------------- MUL_MAT_ID
+
+@pytest.mark.parametrize("ne11", [1, 2])
+def test_mul_mat_id_golden(qmm, golden, ne11):
+    t, k = int(golden["type"]), int(golden["K"])
+    n_used = int(golden["id_n_used"])
+    ids_full = dev(golden["id_ids_full"])
+    ids = ids_full[:, :n_used]                                   # strided view (test-backend-ops.cpp:2097-2102)
+    qmm.set_act_mode(ACT_X86)
+    got = qmm.mul_mat_id(t, dev(golden["id_w"]), k, dev(golden[f"id_b_ne11_{ne11}"]), ids).cpu().numpy()
+    qmm.set_act_mode(ACT_REF)
+    assert rel_rms(got, golden[f"id_dst_ne11_{ne11}"]) < 2e-5
+
+
+@pytest.mark.parametrize("t", ALL, ids=IDS)
+@pytest.mark.parametrize("n_tokens,n_expert,n_used", [(1, 8, 2), (4, 4, 4), (32, 8, 2), (129, 4, 1), (129, 8, 4)])
+def test_mul_mat_id_vs_oracle(qmm, oracle, t, n_tokens, n_expert, n_used):
+    """shapes of test-backend-ops' MUL_MAT_ID family (tests/test-backend-ops.cpp:4229-4258): m=512, k=256"""
+    import ggml_hexagon_amd.synth as synth
+    m, k = 512, 256
+    w = np.stack([synth.synth_weights(t, m, k, seed=e, sigma=0.2) for e in range(n_expert)])
+    rng = np.random.default_rng(n_tokens)
+    ids_full = np.stack([rng.permutation(n_expert) for _ in range(n_tokens)]).astype(np.int32)
+    for ne11 in (1, n_used):
+        b = rng.uniform(-1, 1, (n_tokens, ne11, k)).astype(np.float32)
+        got = qmm.mul_mat_id(t, dev(w), k, dev(b), dev(ids_full)[:, :n_used]).cpu().numpy()
+        want = oracle.mul_mat_id(t, w, k, m, b, ids_full[:, :n_used], ACT_REF)
+        if n_tokens * n_used <= 16:
+            assert rel_rms(got, want) < 2e-5
+        else:
+            assert rel_l2(got, want) < 1e-3
+    qmm.synchronize()
+
+
+def test_mul_mat_id_bad_expert_is_reported(qmm):
+    import ggml_hexagon_amd.synth as synth
+    from ggml_hexagon_amd.capi import QmmError
+    w = dev(np.stack([synth.synth_weights(Q4_K, 16, 256, seed=e) for e in range(2)]))
+    b = torch.ones((1, 1, 256), device="cuda")
+    ids = torch.tensor([[1, 5]], dtype=torch.int32, device="cuda")
+    out = torch.full((1, 2, 16), 3.0, device="cuda")
+    qmm.mul_mat_id(Q4_K, w, 256, b, ids, out=out)
+    with pytest.raises(QmmError):
+        qmm.synchronize()
+    assert (out[0, 1] == 3.0).all()          # the bad slot's row is left untouched
+    qmm.synchronize()                        # flag is cleared
+
+
+# ----------------------------------------------------------------------------- full-size properties
+
+@pytest.mark.parametrize("t", (Q4_0, Q4_K, Q6_K), ids=["q4_0", "q4_K", "q6_K"])
+def test_full_size_properties(qmm, oracle, t):
+    """BASELINE sizes (4096 x 4096 and the 14336-wide FFN): sampled rows against the oracle, and
+    size-independent properties: homogeneity in x (exact for a power-of-two scale: Q8 scales carry it),
+    batch independence (row n of a batch == the same row alone), determinism."""
+    import ggml_hexagon_amd.synth as synth
+    for (m, k) in ((4096, 4096), (4096, 14336)):
+        w = synth.synth_weights(t, m, k, seed=9)
+        wd = dev(w)
+        rng = np.random.default_rng(m + k)
+        x = rng.uniform(-1, 1, (4, k)).astype(np.float32)
+        xd = dev(x)
+        y = qmm.mul_mat(t, wd, k, xd)
+        rows = rng.choice(m, 64, replace=False)
+        want = oracle.mul_mat(t, w[rows], k, x, ACT_REF)
+        assert rel_rms(y.cpu().numpy()[:, rows], want) < 2e-5
+        assert torch.equal(y, qmm.mul_mat(t, wd, k, xd))                       # deterministic
+        assert torch.equal(qmm.mul_mat(t, wd, k, xd * 4.0), y * 4.0)           # exact homogeneity (2^2)
+        y1 = qmm.mul_mat(t, wd, k, xd[2:3].contiguous())
+        assert torch.equal(y1[0], y[2])                                        # batch independence
+        # prefill kernel at full size against the mat-vec kernel (different code path, same math up to f16 rounding)
+        xb = dev(rng.uniform(-1, 1, (64, k)).astype(np.float32))
+        yb = qmm.mul_mat(t, wd, k, xb)
+        ys = torch.cat([qmm.mul_mat(t, wd, k, xb[i:i + 8].contiguous()) for i in range(0, 64, 8)])
+        err = torch.linalg.norm(yb - ys) / torch.linalg.norm(ys)
+        assert float(err) < 1e-3

@@ -111,3 +111,10 @@ def test_synth_weights_are_sane(oracle):
         assert w.shape == (8, synth.row_size(t, 1024)) and synth.row_size(t, 1024) == oracle.row_size(t, 1024)
         d = oracle.dequantize(t, w, 1024)
         assert np.isfinite(d).all() and 0.002 < d.std() < 0.2
+
+
+def test_q8_K_double_rounding_ties_live(oracle, ref):
+    """the reference rounds iscale*x to f32 BEFORE the magic add (no FMA in its build): pin that on adversarial rows"""
+    from helpers import q8_K_tie_rows
+    x = q8_K_tie_rows(2, 512, seed=1)
+    assert np.array_equal(oracle.quantize_act(Q4_K, x), ref.quantize_act(Q4_K, x, "cpu"))
