@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py — llama-bench's pp512 / tg128 protocol over the offloaded surface (quantized MUL_MAT / MUL_MAT_ID).
+
+One *step* is one llama-bench repetition (examples/llama-bench/llama-bench.cpp:1430-1468, 1620-1642) restricted
+to the hot path: a 512-token prompt batch through every MUL_MAT of the model (pp512), then 128 single-token
+passes (tg128).  Weights are synthetic (random valid quant blocks of the model's shapes and types), activations
+synthetic, everything resident in HBM before the timed region.  tok/s = tokens / time of that part, as llama-bench
+computes it; `value` is the tg128 rate (the HBM-bound mat-vec path), `pp512_tok_s` is reported beside it.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 = ggml row split: every weight's rows are sharded over the ranks (one process per GPU) and the partial
+results are concatenated with RCCL all-gather over xGMI after each MUL_MAT group ("scaling": "strong").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak ~2.5 PF (spec)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def roofline_leg(hp, q, n_tokens, torch):
+    """per-launch HIP-event timing of one eager pass, with the GPU kept busy by a spin kernel while the host
+    enqueues (so the event pairs bracket back-to-back kernels, not host launch gaps)"""
+    x, dst_local, _, ids = hp.prepare(n_tokens)
+    recs = []
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(2.0e8))
+    for grp in hp.wl.groups:
+        m0 = grp.mats[0]
+        if m0.n_expert:
+            for m in grp.mats:
+                ne11 = m.n_used if m.name.endswith("down_exps") else 1
+                w, _ = hp.weights[m.name]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                q.mul_mat_id(m.type, w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=dst_local[("id", m.M)])
+                e1.record()
+                recs.append((("id", m.type), m.algo_bytes(n_tokens), m.flops(n_tokens), e0, e1))
+            continue
+        # one launch per run of same-type weights inside the group (that is how qmm_mul_mat_group issues them)
+        i = 0
+        while i < len(grp.mats):
+            j = i
+            while j < len(grp.mats) and grp.mats[j].type == grp.mats[i].type:
+                j += 1
+            if n_tokens > 8:
+                j = i + 1
+            ws, outs, nbytes, fl = [], [], 0, 0
+            for m in grp.mats[i:j]:
+                w, _ = hp.weights[m.name]
+                ws.append((m.type, w))
+                outs.append(dst_local[(m.name.split(".")[-1], w.shape[0])])
+                rows = w.shape[0]
+                nbytes += w.numel() + n_tokens * rows * 4
+                fl += 2 * rows * m.K * n_tokens
+            nbytes += n_tokens * m0.K * 4
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            q.mul_mat_group(ws, m0.K, x[m0.K], outs)
+            e1.record()
+            recs.append((("mm", grp.mats[i].type), nbytes, fl, e0, e1))
+            i = j
+    torch.cuda.synchronize()
+    agg = {}
+    for key, nb, fl, e0, e1 in recs:
+        a = agg.setdefault(key, [0, 0, 0.0, 0])
+        a[0] += nb
+        a[1] += fl
+        a[2] += e0.elapsed_time(e1) * 1e-3
+        a[3] += 1
+    return agg
+
+
+def cpu_baseline(wl, cores):
+    """the reference's CPU backend (oracle/_ref, built from /root/reference) or, failing that, our C port, timed on
+    this host on a bounded sample: the MUL_MATs of one 'more-bits' and one ordinary layer + the output projection
+    at N=1, one ordinary layer at N=512; extrapolated over the layers"""
+    import numpy as np
+    from oracle.pyoracle import Oracle, RefGgml, ref_available
+    from ggml_hexagon_amd import synth
+    kind = "reference" if ref_available() else "port"
+    ref = RefGgml() if kind == "reference" else None
+    orc = None if ref else Oracle()
+    mats = [m for m in wl.all_mats() if not m.n_expert]
+    per_layer = (len(mats) - 1) // wl.n_layer
+    shapes = {}
+    for m in mats:
+        shapes.setdefault((m.type, m.K, m.M), 0)
+        shapes[(m.type, m.K, m.M)] += 1
+    t_tg, t_pp, spent = 0.0, 0.0, time.perf_counter()
+    rng = np.random.default_rng(0)
+    for (t, K, M), count in shapes.items():
+        Ms = min(M, 16384)                    # the 128k-row output matrix is sampled by rows
+        w = synth.synth_weights(t, Ms, K, seed=1)
+        x1 = rng.uniform(-1, 1, (1, K)).astype(np.float32)
+        if ref:
+            _, dt = ref.graph_mul_mat(t, w, K, x1, n_threads=cores, repeat=3)
+        else:
+            t0 = time.perf_counter(); orc.mul_mat(t, w, K, x1); dt = time.perf_counter() - t0
+        t_tg += dt * (M / Ms) * count
+        if time.perf_counter() - spent < 25.0:
+            xp = rng.uniform(-1, 1, (512, K)).astype(np.float32)
+            Mp = min(Ms, 4096)
+            if ref:
+                _, dp = ref.graph_mul_mat(t, w[:Mp], K, xp, n_threads=cores, repeat=1)
+            else:
+                t0 = time.perf_counter(); orc.mul_mat(t, w[:Mp], K, xp[:32]); dp = (time.perf_counter() - t0) * 16
+            t_pp += dp * (M / Mp) * count
+        else:
+            t_pp = float("nan")
+    return {"value": round(1.0 / t_tg, 3), "unit": "tok/s (tg128)", "pp512_tok_s": None if t_pp != t_pp else round(512.0 / t_pp, 2),
+            "cores": cores, "kind": kind, "variant": getattr(ref, "variant", "scalar+omp"),
+            "sample": f"each distinct (type,K,M) of {wl.name} once at N=1 (x3) and N=512 (rows capped at 16384/4096, scaled), "
+                      f"summed over the model's {len(mats)} MUL_MATs; {per_layer} per layer"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("QMM_WORKLOAD", "llama3-8b-q4_k_m"))
+    ap.add_argument("--n-prompt", type=int, default=512)
+    ap.add_argument("--n-gen", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ggml_hexagon_amd import workload
+    from ggml_hexagon_amd.capi import Qmm
+    from ggml_hexagon_amd.hotpath import HotPath
+    from ggml_hexagon_amd.rowsplit import RowConcat
+    from ggml_hexagon_amd.synth import NAMES
+
+    q = Qmm(local)
+    wl = workload.get(args.workload)
+    concat = RowConcat() if world > 1 else None
+    hp = HotPath(q, wl, dev, rank, world, concat)
+    hp.prepare(args.n_prompt)
+    hp.prepare(1)
+    use_graph = world == 1 and not args.no_graph
+    graph = hp.capture(1) if use_graph else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(e=None):
+        if e: e[0].record()
+        hp.run(args.n_prompt)
+        if e: e[1].record()
+        for _ in range(args.n_gen):
+            if graph is not None:
+                graph.replay()
+            else:
+                hp.run(1)
+        if e: e[2].record()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(ev[i])
+    barrier()
+    wall = time.perf_counter() - t0
+
+    pp_s = sum(e[0].elapsed_time(e[1]) for e in ev) * 1e-3 / args.steps
+    tg_s = sum(e[1].elapsed_time(e[2]) for e in ev) * 1e-3 / args.steps
+    times = torch.tensor([wall, pp_s, tg_s], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    wall, pp_s, tg_s = times.tolist()
+
+    tg_tok_s = args.n_gen / tg_s
+    pp_tok_s = args.n_prompt / pp_s
+
+    # ---- roofline leg: per-launch HIP events (this rank's shard of the work)
+    agg1 = roofline_leg(hp, q, 1, torch)
+    aggp = roofline_leg(hp, q, args.n_prompt, torch)
+
+    def dominant(agg):
+        key = max(agg, key=lambda k: agg[k][2])
+        nb, fl, sec, cnt = agg[key]
+        return key, nb, fl, sec, cnt
+
+    k1, nb1, fl1, s1, c1 = dominant(agg1)
+    kp, nbp, flp, sp, cp = dominant(aggp)
+    traffic = None
+    tf = ROOT / "profiles" / "pmc_traffic.json"
+    if tf.exists():
+        try:
+            traffic = json.loads(tf.read_text()).get("matvec_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roof = {"bound": "hbm", "kernel": f"qmm::matvec_kernel<{NAMES.get(k1[1], k1[1])},1>" if k1[0] == "mm" else f"qmm::matvec_id_kernel<{NAMES.get(k1[1])}>",
+            "achieved": round(nb1 / s1 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb1 / s1 / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "launches": c1, "avg_launch_us": round(s1 / c1 * 1e6, 2), "algo_bytes_per_launch": int(nb1 / c1),
+            "all_tg_launches_GBs": round(sum(a[0] for a in agg1.values()) / sum(a[2] for a in agg1.values()) / 1e9, 1)}
+    roof_pp = {"bound": "mfma", "kernel": f"qmm::mfma_kernel<{NAMES.get(kp[1], kp[1])}> (+prep_act)",
+               "achieved": round(flp / sp / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flp / sp / 1e12 / MFMA_PEAK_TFLOPS, 4),
+               "launches": cp, "avg_launch_us": round(sp / cp * 1e6, 2)}
+
+    out = {
+        "metric": "llama-bench pp512 & tg128 tok/s over the offloaded quantized MUL_MAT/MUL_MAT_ID path (value = tg128)",
+        "value": round(tg_tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "int8 dot (tg) / f16 MFMA on Q8-quantized activations (pp), f32 accumulate",
+        "data": "synthetic",
+        "config": {"workload": f"{wl.name}: {len(wl.all_mats())} MUL_MATs/pass, {wl.weight_bytes() / 1e9:.2f} GB quantized weights, "
+                               f"pp{args.n_prompt} + tg{args.n_gen} per step", "n_prompt": args.n_prompt, "n_gen": args.n_gen,
+                   "parallelism": "single GPU" if world == 1 else f"ggml row split over {world} GPUs, RCCL all-gather concat",
+                   "tg_launch": "hipGraph replay" if graph is not None else "eager"},
+        "tg128_tok_s": round(tg_tok_s, 2), "pp512_tok_s": round(pp_tok_s, 2),
+        "tg_ms_per_token": round(tg_s / args.n_gen * 1e3, 4), "pp_ms_per_batch": round(pp_s * 1e3, 3),
+        "tg_algo_GBs": round(wl.algo_bytes(1) / world / (tg_s / args.n_gen) / 1e9, 1),
+        "pp_algo_TFLOPs": round(wl.flops(args.n_prompt) / world / pp_s / 1e12, 1),
+        "roofline": roof, "roofline_pp": roof_pp,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cores = min(len(os.sched_getaffinity(0)), 64)
+            out["cpu_baseline"] = cpu_baseline(wl, cores)
+        except Exception as e:          # the baseline is reported-only; never let it take the GPU numbers down
+            out["cpu_baseline"] = {"value": None, "unit": "tok/s (tg128)", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

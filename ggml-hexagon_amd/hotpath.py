@@ -1,0 +1,107 @@
+"""Drives the offloaded surface — every MUL_MAT / MUL_MAT_ID of one forward pass — through the C-ABI,
+with weights, activations and outputs resident in HBM.  This is what bench.py times: one `run(n_tokens)`
+is what llama.cpp's scheduler hands to the backend for one ubatch (n_tokens = 512 for pp512, 1 for tg128),
+minus the host-side glue ops that are outside the offloaded surface.
+
+Multi-GPU (one process per GPU): ggml row split — rank r holds rows [lo_r, hi_r) of every weight
+(rowsplit.row_range), computes its slice of dst, and the slices are concatenated over RCCL after each
+group of MUL_MATs that share src1.  MUL_MAT_ID is not row-split (the reference tree's row split
+excludes it too, ggml-cuda.cu:1973), so MoE workloads run on one GPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import rowsplit, synth
+from .workload import Workload
+
+
+class HotPath:
+    def __init__(self, qmm, wl: Workload, device, rank: int = 0, world: int = 1, concat=None, seed: int = 1234):
+        self.q, self.wl, self.dev, self.rank, self.world, self.concat = qmm, wl, device, rank, world, concat
+        self.weights = {}       # name -> (uint8 tensor [rows, row_bytes] | [n_expert, M, row_bytes], ranges)
+        i = 0
+        for g in wl.groups:
+            for m in g.mats:
+                i += 1
+                if m.n_expert:
+                    if world != 1:
+                        raise RuntimeError("MUL_MAT_ID workloads are not row-split; run with --gpus 1")
+                    w = synth.synth_weights_torch(m.type, m.n_expert * m.M, m.K, device, seed + i).reshape(m.n_expert, m.M, -1)
+                    self.weights[m.name] = (w, None)
+                else:
+                    ranges = rowsplit.all_ranges(m.M, world)
+                    lo, hi = ranges[rank]
+                    w = synth.synth_weights_torch(m.type, hi - lo, m.K, device, seed + 1000 * rank + i)
+                    self.weights[m.name] = (w, ranges)
+        self.io = {}
+
+    def weight_bytes_local(self) -> int:
+        return sum(w.numel() for w, _ in self.weights.values())
+
+    def prepare(self, n_tokens: int, seed: int = 7):
+        """activations (one per distinct K) and dst buffers for a batch size; synthetic, resident in HBM"""
+        if n_tokens in self.io:
+            return self.io[n_tokens]
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(seed + n_tokens)
+        x, dst_local, dst_full, ids = {}, {}, {}, None
+        for grp in self.wl.groups:
+            for m in grp.mats:
+                if m.n_expert:
+                    ne11 = m.n_used if m.name.endswith("down_exps") else 1
+                    key = (m.K, ne11)
+                    if key not in x:
+                        x[key] = torch.rand((n_tokens, ne11, m.K), device=self.dev, generator=g) * 2 - 1
+                    if ids is None:     # per token: a shuffle of the experts, first n_used taken (test-backend-ops.cpp:2113-2132)
+                        ids = torch.stack([torch.randperm(m.n_expert, device=self.dev, generator=g) for _ in range(n_tokens)]).to(torch.int32)
+                    dkey = ("id", m.M)
+                    if dkey not in dst_local:
+                        dst_local[dkey] = torch.empty((n_tokens, m.n_used, m.M), device=self.dev)
+                else:
+                    if m.K not in x:
+                        x[m.K] = torch.rand((n_tokens, m.K), device=self.dev, generator=g) * 2 - 1
+                    w, ranges = self.weights[m.name]
+                    rows = w.shape[0]
+                    # grouped launches write distinct buffers; different groups may share them
+                    dkey = (m.name.split(".")[-1], rows)
+                    if dkey not in dst_local:
+                        dst_local[dkey] = torch.empty((n_tokens, rows), device=self.dev)
+                    if self.world > 1 and dkey not in dst_full:
+                        dst_full[dkey] = torch.empty((n_tokens, m.M), device=self.dev)
+        self.io[n_tokens] = (x, dst_local, dst_full, ids)
+        return self.io[n_tokens]
+
+    def run(self, n_tokens: int):
+        """issue the whole pass on the current stream (asynchronous)"""
+        x, dst_local, dst_full, ids = self.prepare(n_tokens)
+        q = self.q
+        for grp in self.wl.groups:
+            m0 = grp.mats[0]
+            if m0.n_expert:
+                for m in grp.mats:
+                    ne11 = m.n_used if m.name.endswith("down_exps") else 1
+                    w, _ = self.weights[m.name]
+                    q.mul_mat_id(m.type, w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=dst_local[("id", m.M)])
+                continue
+            ws, outs, keys = [], [], []
+            for m in grp.mats:
+                w, ranges = self.weights[m.name]
+                dkey = (m.name.split(".")[-1], w.shape[0])
+                ws.append((m.type, w))
+                outs.append(dst_local[dkey])
+                keys.append((dkey, ranges))
+            q.mul_mat_group(ws, m0.K, x[m0.K], outs)
+            if self.world > 1:
+                for (dkey, ranges), o in zip(keys, outs):
+                    self.concat.concat(o, ranges, out=dst_full[dkey])
+
+    def capture(self, n_tokens: int):
+        """hipGraph of one pass (single GPU): removes the per-launch host cost from the token-generation loop"""
+        self.prepare(n_tokens)
+        self.run(n_tokens)                  # warm: lazy module loads, workspace growth happen outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run(n_tokens)
+        return g

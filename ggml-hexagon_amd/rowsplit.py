@@ -1,0 +1,63 @@
+"""ggml row split for one-process-per-GPU runs: which weight rows a rank owns, and the concat step.
+
+Partitioning follows the reference tree's only row-split implementation (behavioural spec,
+ggml/src/ggml-cuda/ggml-cuda.cu:727-753): cumulative fractions `tensor_split`, row_low = nrows*split[id]
+rounded DOWN to `rounding`, the last device takes the remainder.  The exchange is a concat, not a sum:
+every rank computes dst[:, row_low:row_high] and the slices are gathered over RCCL (xGMI); no reduction.
+"""
+from __future__ import annotations
+
+ROW_ROUNDING = 64        # mat-vec: one row per wave, MFMA tiles: 64/128 weight rows
+
+
+def row_range(nrows: int, rank: int, world: int, tensor_split=None, rounding: int = ROW_ROUNDING):
+    if tensor_split is None:
+        tensor_split = [i / world for i in range(world)]           # equal devices: cumulative starts
+    lo = int(nrows * tensor_split[rank])
+    lo -= lo % rounding
+    if rank == world - 1:
+        hi = nrows
+    else:
+        hi = int(nrows * tensor_split[rank + 1])
+        hi -= hi % rounding
+    return lo, hi
+
+
+def all_ranges(nrows: int, world: int, tensor_split=None, rounding: int = ROW_ROUNDING):
+    return [row_range(nrows, r, world, tensor_split, rounding) for r in range(world)]
+
+
+class RowConcat:
+    """Gathers per-rank dst slices [N, rows_r] into the full dst [N, M] on every rank.
+
+    Equal slices use one all_gather_into_tensor (RCCL ring/direct over xGMI) into a [world, N, rows] staging
+    buffer followed by one permute-copy; ragged slices (last rank takes the remainder) use all_gather with
+    per-rank tensors.  Works unchanged with the gloo backend on CPU tensors (tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def concat(self, local, ranges, out=None):
+        import torch
+        n = local.shape[0]
+        m = ranges[-1][1]
+        sizes = [hi - lo for lo, hi in ranges]
+        if out is None:
+            out = torch.empty((n, m), dtype=local.dtype, device=local.device)
+        if self.world == 1:
+            out.copy_(local)
+            return out
+        if len(set(sizes)) == 1 and local.is_contiguous():
+            stage = torch.empty((self.world, n, sizes[0]), dtype=local.dtype, device=local.device)
+            self.dist.all_gather_into_tensor(stage, local, group=self.group)
+            out.view(n, self.world, sizes[0]).copy_(stage.permute(1, 0, 2))
+        else:
+            parts = [torch.empty((n, s), dtype=local.dtype, device=local.device) for s in sizes]
+            self.dist.all_gather(parts, local.contiguous(), group=self.group)
+            for (lo, hi), p in zip(ranges, parts):
+                out[:, lo:hi] = p
+        return out

@@ -47,3 +47,32 @@ def synth_weights(t: int, rows: int, k: int, seed: int = 0, sigma: float = 0.02)
     else:
         raise ValueError(t)
     return blk.reshape(rows, -1)
+
+
+def synth_weights_torch(t: int, rows: int, k: int, device, seed: int = 0, sigma: float = 0.02):
+    """same construction as synth_weights, generated directly in HBM (bench-sized tensors)"""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    nb = rows * (k // BLCK[t])
+    blk = torch.randint(0, 256, (nb, TYPE_SIZE[t]), dtype=torch.uint8, device=device, generator=g)
+
+    def f16(scale, signed=True):
+        v = (torch.rand(nb, device=device, generator=g) + 0.5) * scale
+        if signed:
+            v = v * (torch.randint(0, 2, (nb,), device=device, generator=g).float() * 2 - 1)
+        return v.to(torch.float16).view(torch.uint8).reshape(nb, 2)
+
+    if t == Q4_0:
+        blk[:, 0:2] = f16(3 * sigma / 8)
+    elif t == Q8_0:
+        blk[:, 0:2] = f16(3 * sigma / 127)
+    elif t in (Q4_K, Q5_K):
+        qmax = 15 if t == Q4_K else 31
+        blk[:, 0:2] = f16(6 * sigma / qmax / 40, signed=False)
+        blk[:, 2:4] = f16(3 * sigma / 40, signed=False)
+    elif t == Q6_K:
+        blk[:, 208:210] = f16(3 * sigma / 32 / 80)
+    else:
+        raise ValueError(t)
+    return blk.reshape(rows, -1)

@@ -1,0 +1,114 @@
+"""The MUL_MAT / MUL_MAT_ID sequence one llama.cpp forward pass issues, per model config of BASELINE.json.
+
+llama.cpp builds, per layer (src/llama-model.cpp:4191-4350 llm_build_llama): wq, wk, wv (same src1), wo,
+ffn gate + up (same src1), ffn down; after the last layer the output projection.  MoE models replace the
+FFN by three MUL_MAT_ID over n_expert stacked matrices (src/llama-graph.cpp:870-894).  Weight types follow
+llama-quant.cpp's recipes (Q4_K_M: use_more_bits layers get Q6_K for attn_v and ffn_down, output Q6_K;
+src/llama-quant.cpp:129-131, 166-168, 235-236, 291-297).  Only the shapes and types matter here: the
+weights are synthetic (synth.py) and llama-bench feeds random token ids (examples/llama-bench/llama-bench.cpp:1443-1466).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+from .synth import Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, row_size
+
+
+@dataclass
+class MatMul:
+    name: str
+    type: int
+    K: int
+    M: int
+    n_expert: int = 0          # > 0: MUL_MAT_ID over n_expert matrices, n_used of them per token
+    n_used: int = 0
+
+    @property
+    def weight_bytes(self) -> int:
+        return row_size(self.type, self.K) * self.M * max(self.n_expert, 1)
+
+    def algo_bytes(self, n_tokens: int) -> int:
+        """weights read once (for MoE: the experts actually used, bounded by n_expert) + src1 + dst"""
+        if self.n_expert:
+            used = min(self.n_expert, self.n_used * n_tokens)
+            return row_size(self.type, self.K) * self.M * used + n_tokens * self.K * 4 + n_tokens * self.n_used * self.M * 4
+        return self.weight_bytes + n_tokens * self.K * 4 + n_tokens * self.M * 4
+
+    def flops(self, n_tokens: int) -> int:
+        return 2 * self.M * self.K * n_tokens * (self.n_used if self.n_expert else 1)
+
+
+@dataclass
+class Group:
+    """MUL_MATs that share src1 (issued as one grouped launch when batch <= 8)"""
+    mats: list
+
+
+@dataclass
+class Workload:
+    name: str
+    n_layer: int
+    n_embd: int
+    groups: list = field(default_factory=list)     # per-token sequence of Groups (all layers + output)
+
+    def all_mats(self):
+        return [m for g in self.groups for m in g.mats]
+
+    def weight_bytes(self) -> int:
+        return sum(m.weight_bytes for m in self.all_mats())
+
+    def algo_bytes(self, n_tokens: int) -> int:
+        return sum(m.algo_bytes(n_tokens) for m in self.all_mats())
+
+    def flops(self, n_tokens: int) -> int:
+        return sum(m.flops(n_tokens) for m in self.all_mats())
+
+
+def use_more_bits(i: int, n: int) -> bool:      # src/llama-quant.cpp:129-131
+    return i < n // 8 or i >= 7 * n // 8 or (i - n // 8) % 3 == 2
+
+
+def _llama(name, n_layer, n_embd, n_ff, n_head, n_head_kv, n_vocab, recipe, n_expert=0, n_used=0) -> Workload:
+    kv = n_embd // n_head * n_head_kv
+    w = Workload(name, n_layer, n_embd)
+    for i in range(n_layer):
+        more = use_more_bits(i, n_layer)
+        if recipe == "q4_0":
+            tq = tk = tv = to = tg = td = Q4_0
+        elif recipe == "q4_k":                       # north-star synthetic: every matmul weight Q4_K
+            tq = tk = tv = to = tg = td = Q4_K
+        else:                                        # q4_k_m
+            tq = tk = to = tg = Q4_K
+            tv = td = Q6_K if more else Q4_K
+            if n_layer >= 80 and tv == Q4_K:         # 70B rule: attn_v Q4_K -> Q5_K (llama-quant.cpp:237-243)
+                tv = Q5_K
+            if n_expert == 8:                        # llama-quant.cpp:244-255, 314-322
+                tk = tv = Q8_0
+                to = Q5_K
+        w.groups.append(Group([MatMul(f"blk.{i}.attn_q", tq, n_embd, n_embd), MatMul(f"blk.{i}.attn_k", tk, n_embd, kv),
+                               MatMul(f"blk.{i}.attn_v", tv, n_embd, kv)]))
+        w.groups.append(Group([MatMul(f"blk.{i}.attn_output", to, n_embd, n_embd)]))
+        if n_expert:
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_gate_exps", tg, n_embd, n_ff, n_expert, n_used)]))
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_up_exps", tg, n_embd, n_ff, n_expert, n_used)]))
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_down_exps", td, n_ff, n_embd, n_expert, n_used)]))
+        else:
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_gate", tg, n_embd, n_ff), MatMul(f"blk.{i}.ffn_up", tg, n_embd, n_ff)]))
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_down", td, n_ff, n_embd)]))
+    out_t = {"q4_0": Q6_K, "q4_k": Q4_K}.get(recipe, Q6_K)   # stock Q4_0 files carry a Q6_K output tensor
+    w.groups.append(Group([MatMul("output", out_t, n_embd, n_vocab)]))
+    return w
+
+
+WORKLOADS = {
+    # BASELINE.json configs[1..4] + the north-star synthetic model
+    "llama2-7b-q4_0":     lambda: _llama("llama2-7b-q4_0", 32, 4096, 11008, 32, 32, 32000, "q4_0"),
+    "llama3-8b-q4_k_m":   lambda: _llama("llama3-8b-q4_k_m", 32, 4096, 14336, 32, 8, 128256, "q4_k_m"),
+    "llama3-70b-q4_k_m":  lambda: _llama("llama3-70b-q4_k_m", 80, 8192, 28672, 64, 8, 128256, "q4_k_m"),
+    "mixtral-8x7b-q4_k_m": lambda: _llama("mixtral-8x7b-q4_k_m", 32, 4096, 14336, 32, 8, 32000, "q4_k_m", 8, 2),
+    "synth-7b-q4_k":      lambda: _llama("synth-7b-q4_k", 32, 4096, 11008, 32, 32, 32000, "q4_k"),
+}
+
+
+def get(name: str) -> Workload:
+    return WORKLOADS[name]()
