@@ -20,9 +20,9 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
 __device__ __forceinline__ void q8_0_block(const float4 v, int act_mode, uint32_t & packed, float & d_out) {
 #pragma clang fp contract(off)
     float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, WAVE));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, WAVE));
-    amax = fmaxf(amax, __shfl_xor(amax, 4, WAVE));
+    amax = fmaxf(amax, dpp_mov<DPP_QUAD_X1>(amax));          // the block's 8 lanes: two quads ...
+    amax = fmaxf(amax, dpp_mov<DPP_QUAD_X2>(amax));
+    amax = fmaxf(amax, dpp_mov<DPP_ROW_HALF_MIRROR>(amax));   // ... mirrored within each group of 8
     const float d = __fdiv_rn(amax, 127.0f);
     d_out = __half2float(__float2half_rn(d));                  // y[i].d = GGML_FP32_TO_FP16(d)
     int q0, q1, q2, q3;
@@ -48,22 +48,21 @@ __device__ __forceinline__ int magic_round(float prod) {
 }
 
 // One Q8_K block (256 floats) is handled by a whole wave, lane l holding elements 4l..4l+3.
-// Returns the packed 4 int8; d_out (all lanes) ; bsum valid in lanes with (lane & 3) == 0 -> group lane/4.
+// Returns the packed 4 int8; d_out (all lanes); bsum = sum over the lane's group of 16 (BSG == 16: 4 lanes)
+// or 32 (BSG == 32: 8 lanes) activations, valid in every lane of the group.
+template <int BSG>
 __device__ __forceinline__ void q8_K_block(const float4 v, int lane, uint32_t & packed, float & d_out, int & bsum) {
 #pragma clang fp contract(off)      // the product must round to f32 BEFORE the magic add (hipcc contracts __fmul_rn/__fadd_rn too)
-    // first element with the largest |x| decides the sign of the scale (strict '>' scan in the reference)
+    // first element with the largest |x| decides the sign of the scale (strict '>' scan in the reference):
+    // wave max of |x| on DPP, then the lowest lane that holds it supplies its own first maximum
     float best = fabsf(v.x), bval = v.x;
-    int   bidx = 4 * lane;
-    if (fabsf(v.y) > best) { best = fabsf(v.y); bval = v.y; bidx = 4 * lane + 1; }
-    if (fabsf(v.z) > best) { best = fabsf(v.z); bval = v.z; bidx = 4 * lane + 2; }
-    if (fabsf(v.w) > best) { best = fabsf(v.w); bval = v.w; bidx = 4 * lane + 3; }
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const float ob = __shfl_xor(best, off, WAVE);
-        const float ov = __shfl_xor(bval, off, WAVE);
-        const int   oi = __shfl_xor(bidx, off, WAVE);
-        if (ob > best || (ob == best && oi < bidx)) { best = ob; bval = ov; bidx = oi; }
-    }
+    if (fabsf(v.y) > best) { best = fabsf(v.y); bval = v.y; }
+    if (fabsf(v.z) > best) { best = fabsf(v.z); bval = v.z; }
+    if (fabsf(v.w) > best) { best = fabsf(v.w); bval = v.w; }
+    const float gmax = wave_max(best);
+    const unsigned long long holders = __ballot(best == gmax);
+    bval = readlane_f(bval, __builtin_amdgcn_readfirstlane((int) __ffsll((long long) holders) - 1));
+    best = gmax;
     if (best == 0.0f) {            // reference: d = 0, qs = 0 (bsums left as they were; we define 0)
         packed = 0; d_out = 0.0f; bsum = 0;
         return;
@@ -75,8 +74,9 @@ __device__ __forceinline__ void q8_K_block(const float4 v, int lane, uint32_t & 
     const int q3 = min(127, magic_round(__fmul_rn(iscale, v.w)));
     packed = pack4(q0, q1, q2, q3);
     int s = q0 + q1 + q2 + q3;
-    s += __shfl_xor(s, 1, WAVE);
-    s += __shfl_xor(s, 2, WAVE);
+    s += dpp_mov_i<DPP_QUAD_X1>(s);
+    s += dpp_mov_i<DPP_QUAD_X2>(s);
+    if (BSG == 32) s += dpp_mov_i<DPP_ROW_HALF_MIRROR>(s);
     bsum  = s;
     d_out = __fdiv_rn(1.0f, iscale);
 }
@@ -84,7 +84,7 @@ __device__ __forceinline__ void q8_K_block(const float4 v, int lane, uint32_t & 
 // Quantize `rows` activation rows of length K into (q, d, bsum).  All threads of the block take part;
 // the caller synchronizes afterwards.  ACT = T_Q8_0 or T_Q8_K.  Row r of x starts at x + r*ldx;
 // outputs for row r at q + r*K, d + r*(K/blk), bsum + r*(K/16).
-template <int ACT>
+template <int ACT, int BSG = 16, int SWZ = 0>
 __device__ __forceinline__ void quantize_rows(const float * __restrict__ x, int64_t ldx, int rows, int K, int act_mode,
                                               int8_t * q, float * d, int16_t * bsum, int tid, int nthreads) {
     if (ACT == T_Q8_0) {
@@ -98,7 +98,7 @@ __device__ __forceinline__ void quantize_rows(const float * __restrict__ x, int6
             uint32_t p; float dd;
             q8_0_block(v, act_mode, p, dd);
             if (live) {
-                *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + 4 * c) = p;
+                *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + act_pos<SWZ>(4 * c)) = p;
                 if ((c & 7) == 0) d[(int64_t) r * (K / 32) + c / 8] = dd;
             }
         }
@@ -109,10 +109,11 @@ __device__ __forceinline__ void quantize_rows(const float * __restrict__ x, int6
             const int r = blk / nb, b = blk % nb;
             const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t) r * ldx + b * 256 + 4 * lane);
             uint32_t p; float dd; int bs;
-            q8_K_block(v, lane, p, dd, bs);
-            *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + b * 256 + 4 * lane) = p;
+            q8_K_block<BSG>(v, lane, p, dd, bs);
+            *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + act_pos<SWZ>(b * 256 + 4 * lane)) = p;
             if (lane == 0) d[(int64_t) r * nb + b] = dd;
-            if (bsum && (lane & 3) == 0) bsum[(int64_t) r * (K / 16) + b * 16 + lane / 4] = (int16_t) bs;
+            constexpr int LPG = BSG / 4;                         // lanes per bsum group
+            if (bsum && (lane & (LPG - 1)) == 0) bsum[(int64_t) r * (K / BSG) + b * (256 / BSG) + lane / LPG] = (int16_t) bs;
         }
     }
 }

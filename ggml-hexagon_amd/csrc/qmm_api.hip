@@ -39,13 +39,12 @@ static int launch_matvec_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, c
     auto kern = matvec_kernel<T, NTOK>;
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     const int total = g.row_end[g.n - 1];
-    // waves per block: 16 (one block per CU covers 16 rows); small problems use smaller blocks to spread over CUs
-    int nw = 16;
-    while (nw > 4 && (total + nw - 1) / nw < c->cus) nw >>= 1;
-    if (lds > 80 * 1024) nw = 16;
+    // one block per CU (the activation vector is quantized once per CU); 16 waves per block unless there are
+    // fewer rows than that per CU.  Every wave gets a contiguous chunk of rows (+-1 row balance).
+    int nw = (total + c->cus - 1) / c->cus;
+    nw = nw >= 16 ? 16 : nw > 8 ? 16 : nw > 4 ? 8 : 4;
     int blocks = (total + nw - 1) / nw;
-    const int cap = c->cus * (lds > 80 * 1024 ? 1 : 2);
-    if (blocks > cap) blocks = cap;
+    if (blocks > c->cus * c->mv_bpc) blocks = c->cus * c->mv_bpc;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * WAVE), lds, st, g, x, ldx, K, c->act_mode);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
@@ -123,6 +122,8 @@ qmm_ctx * qmm_create(int device) {
     }
     const char * e = getenv("GGML_MI355X_ACT_MODE");
     if (e) c->act_mode = atoi(e) ? QMM_ACT_X86 : QMM_ACT_REF;
+    e = getenv("GGML_MI355X_MV_BPC");
+    if (e && atoi(e) >= 1 && atoi(e) <= 8) c->mv_bpc = atoi(e);
     e = getenv("GGML_MI355X_PREC");
     if (e) c->prec = (!strcmp(e, "bf16") || !strcmp(e, "0")) ? QMM_PREC_BF16 : QMM_PREC_F16_Q8;
     return c;
@@ -155,7 +156,7 @@ int qmm_device_info(const qmm_ctx * c, char * name, size_t name_len, size_t * me
 }
 
 int qmm_set_act_mode(qmm_ctx * c, int m) {
-    if (!c || (m != QMM_ACT_REF && m != QMM_ACT_X86)) return fail(QMM_EINVAL, "bad act mode");
+    if (!c || ((m & 0xff) != QMM_ACT_REF && (m & 0xff) != QMM_ACT_X86)) return fail(QMM_EINVAL, "bad act mode");
     c->act_mode = m;
     return QMM_OK;
 }

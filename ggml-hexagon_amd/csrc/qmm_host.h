@@ -18,6 +18,7 @@ struct qmm_ctx {
     int         cus = 0;
     int         act_mode = QMM_ACT_REF;
     int         prec = QMM_PREC_F16_Q8;
+    int         mv_bpc = 1;          // mat-vec blocks per CU (tuning knob, GGML_MI355X_MV_BPC)
     // workspace of the batched path (16-bit activations, row scales, MoE lists); grown on demand
     void *      ws = nullptr;
     size_t      ws_bytes = 0;

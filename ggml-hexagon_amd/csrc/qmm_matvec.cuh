@@ -14,6 +14,7 @@
 #pragma once
 
 #include "qmm_act.cuh"
+#include "qmm_mvunit.cuh"
 
 namespace qmm {
 
@@ -32,10 +33,16 @@ template <int T> __host__ __device__ constexpr int act_block() { return Traits<T
 
 template <int T, int NTOK> __host__ __device__ inline size_t matvec_lds_bytes(int K) {
     size_t b = (size_t) NTOK * K + (size_t) NTOK * (K / act_block<T>()) * 4;
-    if (Traits<T>::ACT == T_Q8_K) b += (size_t) NTOK * (K / 16) * 2;
+    if (Traits<T>::ACT == T_Q8_K) b += (size_t) NTOK * (K / MvUnit<T>::BSG) * 2;
     return (b + 15) & ~(size_t) 15;
 }
 
+// Work split: rows are dealt to waves round-robin (row = wave_id + i * n_waves), so at any moment the
+// chip sweeps one contiguous window of W.  A wave walks a row in slices of 64 units; latency is hidden by
+// the 16 waves per CU (measured: explicit per-wave software pipelining is slower than plain TLP here).
+// Loads are issued unconditionally (unit index clamped) because hipcc drains vmcnt to 0 at every branch
+// that surrounds a global_load.  The first slice of a wave's first row is fetched BEFORE the activation
+// staging so its HBM latency overlaps the in-kernel quantization.
 template <int T, int NTOK>
 __global__ void __launch_bounds__(1024)
 matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t ldx, const int K, const int act_mode) {
@@ -45,70 +52,60 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
     float *   ad = reinterpret_cast<float *>(smem + (size_t) NTOK * K);
     int16_t * ab = reinterpret_cast<int16_t *>(ad + (size_t) NTOK * (K / act_block<T>()));
 
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = blockDim.x / WAVE;
-    const int units = K / Traits<T>::UNIT_W;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE), nwaves = blockDim.x / WAVE;
+    const int units = K / MvUnit<T>::W;
+    const int iters = (units + WAVE - 1) / WAVE;
     const int total_rows = g.row_end[g.n - 1];
+    const int W = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
 
-    // first row of this wave: put its weight loads in flight before the activation staging
-    int row = blockIdx.x * nwaves + wave;
-    Unit<T> pre;
-    const uint8_t * wrow = nullptr;
-    float * drow = nullptr;
-    int64_t ldd = 0;
-    auto locate = [&](int r) {
-        int i = 0, base = 0;
+    auto locate = [&](int r, const uint8_t *& wrow, float *& drow, int64_t & ldd) {
+        int i = 0, b0 = 0;
 #pragma unroll
         for (int k = 0; k < MV_MAX_GROUP - 1; ++k)
-            if (k < g.n - 1 && r >= g.row_end[k]) { i = k + 1; base = g.row_end[k]; }
-        wrow = g.w[i] + (int64_t) (r - base) * g.row_bytes[i];
-        drow = g.dst[i] + (r - base);
+            if (k < g.n - 1 && r >= g.row_end[k]) { i = k + 1; b0 = g.row_end[k]; }
+        wrow = g.w[i] + (int64_t) (r - b0) * g.row_bytes[i];
+        drow = g.dst[i] + (r - b0);
         ldd  = g.ldd[i];
     };
-    const bool have = row < total_rows;
-    if (have) {
-        locate(row);
-        if (lane < units) pre.load(wrow, lane);
-    }
 
-    quantize_rows<ACT>(x, ldx, NTOK, K, act_mode, aq, ad, ACT == T_Q8_K ? ab : nullptr, tid, blockDim.x);
+    const uint8_t * wrow; float * drow; int64_t ldd;
+    locate(min(gw, total_rows - 1), wrow, drow, ldd);
+#ifdef QMM_MV_PREFETCH
+    MvUnit<T> first;
+    first.load(wrow, min(lane, units - 1));
+#endif
+
+    quantize_rows<ACT, MvUnit<T>::BSG, T>(x, ldx, NTOK, K, act_mode, aq, ad, ACT == T_Q8_K ? ab : nullptr, tid, blockDim.x);
     __syncthreads();
 
-    for (; row < total_rows; row += gridDim.x * nwaves) {
+    for (int row = gw; row < total_rows; row += W) {
         float acc[NTOK];
 #pragma unroll
         for (int n = 0; n < NTOK; ++n) acc[n] = 0.0f;
-
-        int u = lane;
-        if (u < units) {                      // first chunk: already in registers
+        for (int it = 0; it < iters; ++it) {
+            const int u = lane + WAVE * it, uc = min(u, units - 1);
+            MvUnit<T> un;
+#ifdef QMM_MV_PREFETCH
+            if (it == 0 && row == gw) un = first;            // wave-uniform
+            else un.load(wrow, uc);
+#else
+            un.load(wrow, uc);
+#endif
 #pragma unroll
-            for (int n = 0; n < NTOK; ++n)
-                acc[n] += pre.dot(u, aq + (size_t) n * K, ad + (size_t) n * (K / act_block<T>()), ab + (size_t) n * (K / 16));
+            for (int n = 0; n < NTOK; ++n) {
+                const float p = un.dot(uc, aq + (size_t) n * K, ad + (size_t) n * (K / act_block<T>()), ab + (size_t) n * (K / MvUnit<T>::BSG));
+                acc[n] += u < units ? p : 0.0f;
+            }
         }
-#pragma unroll 2
-        for (u += WAVE; u < units; u += WAVE) {
-            Unit<T> un;
-            un.load(wrow, u);
-#pragma unroll
-            for (int n = 0; n < NTOK; ++n)
-                acc[n] += un.dot(u, aq + (size_t) n * K, ad + (size_t) n * (K / act_block<T>()), ab + (size_t) n * (K / 16));
-        }
-
-        // next row's first chunk goes in flight before the reduction of this one
-        float * dcur = drow;
-        const int64_t ldcur = ldd;
-        const int next = row + gridDim.x * nwaves;
-        if (next < total_rows) {
-            locate(next);
-            if (lane < units) pre.load(wrow, lane);
-        }
-
         float out = 0.0f;
 #pragma unroll
         for (int n = 0; n < NTOK; ++n) {
-            const float s = wave_sum(acc[n]);
-            if (lane == n) out = s;
+            const float t = wave_sum(acc[n]);
+            if (lane == n) out = t;
         }
-        if (lane < NTOK) dcur[(int64_t) lane * ldcur] = out;
+        if (lane < NTOK) drow[(int64_t) lane * ldd] = out;
+        if (row + W < total_rows) locate(row + W, wrow, drow, ldd);
     }
 }
 

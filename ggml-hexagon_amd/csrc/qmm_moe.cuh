@@ -37,15 +37,15 @@ matvec_id_kernel(const uint8_t * __restrict__ as, const int64_t row_bytes, const
         return;
     }
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = blockDim.x / WAVE;
-    const int units = K / Traits<T>::UNIT_W;
+    const int units = K / MvUnit<T>::W;
     const uint8_t * We = as + (int64_t) e * expert_bytes;
     float * out = dst + (int64_t) t * d_s2 + (int64_t) s * d_s1;
 
     int row = blockIdx.y * nwaves + wave;
-    Unit<T> pre;
+    MvUnit<T> pre;
     if (row < M && lane < units) pre.load(We + (int64_t) row * row_bytes, lane);
 
-    quantize_rows<ACT>(b + (int64_t) t * b_s2 + (int64_t) (s % ne11) * b_s1, 0, 1, K, act_mode, aq, ad,
+    quantize_rows<ACT, MvUnit<T>::BSG, T>(b + (int64_t) t * b_s2 + (int64_t) (s % ne11) * b_s1, 0, 1, K, act_mode, aq, ad,
                        ACT == T_Q8_K ? ab : nullptr, tid, blockDim.x);
     __syncthreads();
 
@@ -56,7 +56,7 @@ matvec_id_kernel(const uint8_t * __restrict__ as, const int64_t row_bytes, const
         if (u < units) acc += pre.dot(u, aq, ad, ab);
 #pragma unroll 2
         for (u += WAVE; u < units; u += WAVE) {
-            Unit<T> un;
+            MvUnit<T> un;
             un.load(wrow, u);
             acc += un.dot(u, aq, ad, ab);
         }
