@@ -51,13 +51,13 @@ def build_plugin(force: bool = False) -> Path | None:
     srcs = [src, ROOT / "include" / "ggml-mi355x.h", ROOT / "include" / "ggml_mi355x_qmm.h"]
     if not force and _newer(PLUGIN_SO, srcs + [QMM_SO]):
         return PLUGIN_SO
-    if not have_ggml_headers() or not shutil.which(HIPCC):
+    if not have_ggml_headers() or not (shutil.which("g++") or shutil.which("c++")):
         return PLUGIN_SO if PLUGIN_SO.exists() else None
-    cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-DGGML_BACKEND_DL", "-DGGML_BACKEND_BUILD", "-DGGML_BACKEND_SHARED",
-           "-DGGML_SHARED", "-D__HIP_PLATFORM_AMD__",
-           f"-I{GGML_SRC / 'include'}", f"-I{GGML_SRC / 'src'}", f"-I{ROOT / 'include'}", "-I/opt/rocm/include",
-           "-x", "c++", str(src), "-o", str(PLUGIN_SO),
-           f"-L{PKG}", "-lggml_mi355x_qmm", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    cxx = shutil.which("g++") or shutil.which("c++")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DGGML_BACKEND_DL", "-DGGML_BACKEND_BUILD",
+           "-DGGML_BACKEND_SHARED", "-DGGML_SHARED",
+           f"-I{GGML_SRC / 'include'}", f"-I{GGML_SRC / 'src'}", f"-I{ROOT / 'include'}",
+           str(src), "-o", str(PLUGIN_SO), f"-L{PKG}", "-lggml_mi355x_qmm", "-Wl,-rpath,$ORIGIN"]
     subprocess.run(cmd, check=True)
     return PLUGIN_SO
 

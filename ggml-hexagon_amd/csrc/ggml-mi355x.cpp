@@ -1,0 +1,431 @@
+// ggml-mi355x.cpp — ggml backend plugin for MI355X: reg / device / buffer type / buffer / backend vtables
+// (contract: ggml/src/ggml-backend-impl.h:17-207) over the kernel C-ABI of include/ggml_mi355x_qmm.h.
+//
+// Mirrors the structure of the reference's "backend per ggml spec" section
+// (ggml/src/ggml-hexagon/ggml-hexagon.cpp:5417-5427 buffer iface, 5708-5737 buffer type, 5818-5834 device iface,
+// 5555-5574 graph_compute node loop, 5065-5115 supports_op gate, 5941-6007 reg, 6066-6125 init, 6127 DL_IMPL),
+// with three deliberate differences:
+//   * buffers are real HBM (is_host = false): weights are uploaded once by set_tensor and never re-marshalled
+//     (the reference re-maps tensor memory through FastRPC per call, ggml-hexagon.cpp:4975-5060);
+//   * op failures are reported as GGML_STATUS_FAILED (the reference logs and continues, :5053-5056);
+//   * consecutive MUL_MAT nodes that share src1 are issued as one grouped launch when the batch is <= 8.
+//
+// This file includes only ggml headers and the C-ABI; all HIP lives in libggml_mi355x_qmm.so.
+
+#include "ggml-mi355x.h"
+#include "ggml-backend-impl.h"
+#include "ggml-impl.h"
+#include "ggml_mi355x_qmm.h"
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct mi355x_device_ctx {
+    int         ordinal = 0;
+    qmm_ctx *   qmm = nullptr;
+    std::string name;
+    std::string description;
+    ggml_backend_buffer_type buft{};
+    std::string buft_name;
+};
+
+struct mi355x_buffer_ctx {
+    mi355x_device_ctx * dev;
+    void *              base;
+};
+
+struct mi355x_backend_ctx {
+    mi355x_device_ctx * dev;
+    std::string         name;
+};
+
+mi355x_device_ctx      g_devs[GGML_MI355X_MAX_DEVICES];
+ggml_backend_device    g_devices[GGML_MI355X_MAX_DEVICES];
+int                    g_ndev = 0;
+
+bool type_supported(enum ggml_type t) {
+    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K;
+}
+
+// ----------------------------------------------------------------------------------------------- buffer
+
+void buffer_free(ggml_backend_buffer_t buffer) {
+    auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    qmm_free(ctx->dev->qmm, ctx->base);
+    delete ctx;
+}
+void * buffer_get_base(ggml_backend_buffer_t buffer) { return ((mi355x_buffer_ctx *) buffer->context)->base; }
+
+enum ggml_status buffer_init_tensor(ggml_backend_buffer_t, struct ggml_tensor *) { return GGML_STATUS_SUCCESS; }
+
+void buffer_memset_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
+    auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    if (qmm_memset(ctx->dev->qmm, (char *) tensor->data + offset, value, size, nullptr) || qmm_synchronize(ctx->dev->qmm, nullptr))
+        GGML_ABORT("MI355X memset_tensor: %s", qmm_last_error());
+}
+void buffer_set_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    if (qmm_memcpy_h2d(ctx->dev->qmm, (char *) tensor->data + offset, data, size, nullptr))
+        GGML_ABORT("MI355X set_tensor: %s", qmm_last_error());
+}
+void buffer_get_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    if (qmm_memcpy_d2h(ctx->dev->qmm, data, (const char *) tensor->data + offset, size, nullptr))
+        GGML_ABORT("MI355X get_tensor: %s", qmm_last_error());
+}
+const char * buft_get_name(ggml_backend_buffer_type_t buft);
+bool buffer_cpy_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    ggml_backend_buffer_t sb = src->view_src ? src->view_src->buffer : src->buffer;
+    if (!sb || sb->buft->iface.get_name != buft_get_name) return false;           // not one of ours: let ggml stage through the host
+    auto * sctx = (mi355x_buffer_ctx *) sb->context;
+    if (sctx->dev != ctx->dev) return false;
+    if (qmm_memcpy_d2d(ctx->dev->qmm, dst->data, src->data, ggml_nbytes(src), nullptr) || qmm_synchronize(ctx->dev->qmm, nullptr))
+        GGML_ABORT("MI355X cpy_tensor: %s", qmm_last_error());
+    return true;
+}
+void buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
+    auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    if (qmm_memset(ctx->dev->qmm, ctx->base, value, buffer->size, nullptr) || qmm_synchronize(ctx->dev->qmm, nullptr))
+        GGML_ABORT("MI355X clear: %s", qmm_last_error());
+}
+
+const ggml_backend_buffer_i buffer_iface = {
+    /* .free_buffer   = */ buffer_free,
+    /* .get_base      = */ buffer_get_base,
+    /* .init_tensor   = */ buffer_init_tensor,
+    /* .memset_tensor = */ buffer_memset_tensor,
+    /* .set_tensor    = */ buffer_set_tensor,
+    /* .get_tensor    = */ buffer_get_tensor,
+    /* .cpy_tensor    = */ buffer_cpy_tensor,
+    /* .clear         = */ buffer_clear,
+    /* .reset         = */ nullptr,
+};
+
+// ----------------------------------------------------------------------------------------------- buffer type
+
+const char * buft_get_name(ggml_backend_buffer_type_t buft) { return ((mi355x_device_ctx *) buft->context)->buft_name.c_str(); }
+
+ggml_backend_buffer_t buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    auto * dev = (mi355x_device_ctx *) buft->context;
+    void * p = qmm_malloc(dev->qmm, size + 256);        // +256: vector loads of the last weight row never leave the allocation
+    if (!p) {
+        GGML_LOG_ERROR("%s: allocating %.2f MiB on %s failed: %s\n", __func__, size / 1048576.0, dev->name.c_str(), qmm_last_error());
+        return nullptr;
+    }
+    return ggml_backend_buffer_init(buft, buffer_iface, new mi355x_buffer_ctx{ dev, p }, size);
+}
+size_t buft_get_alignment(ggml_backend_buffer_type_t) { return 256; }
+size_t buft_get_max_size(ggml_backend_buffer_type_t buft) {
+    auto * dev = (mi355x_device_ctx *) buft->context;
+    size_t f = 0, t = 0;
+    qmm_device_info(dev->qmm, nullptr, 0, &f, &t, nullptr);
+    return t;
+}
+bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
+
+const ggml_backend_buffer_type_i buft_iface = {
+    /* .get_name       = */ buft_get_name,
+    /* .alloc_buffer   = */ buft_alloc_buffer,
+    /* .get_alignment  = */ buft_get_alignment,
+    /* .get_max_size   = */ buft_get_max_size,
+    /* .get_alloc_size = */ nullptr,
+    /* .is_host        = */ buft_is_host,
+};
+
+// ----------------------------------------------------------------------------------------------- ops
+
+bool is_ours(const struct ggml_tensor * t) {
+    ggml_backend_buffer_t b = t->view_src ? t->view_src->buffer : t->buffer;
+    return b && b->buft->iface.get_name == buft_get_name;
+}
+
+// src0 rows must be whole rows of blocks, src1/dst dense f32 rows
+bool mul_mat_shape_ok(const struct ggml_tensor * op) {
+    const ggml_tensor * a = op->src[0], * b = op->src[1];
+    if (!a || !b || !type_supported(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
+    if (a->ne[0] % ggml_blck_size(a->type) || a->ne[0] != b->ne[0]) return false;
+    if (a->nb[0] != ggml_type_size(a->type) || a->nb[1] < ggml_row_size(a->type, a->ne[0])) return false;
+    if (a->nb[1] % 2 || a->nb[2] % 2 || a->nb[3] % 2) return false;
+    if (b->nb[0] != sizeof(float) || b->nb[1] % 16 || b->nb[2] % 16 || b->nb[3] % 16) return false;
+    if (op->nb[0] != sizeof(float) || op->nb[1] % 4 || op->nb[1] < op->ne[0] * sizeof(float)) return false;
+    return true;
+}
+
+bool supports_mul_mat(const struct ggml_tensor * op) {
+    if (!mul_mat_shape_ok(op)) return false;
+    const ggml_tensor * a = op->src[0], * b = op->src[1];
+    if (b->nb[1] < b->ne[0] * sizeof(float)) return false;                          // transposed / permuted src1
+    if (b->ne[2] % a->ne[2] || b->ne[3] % a->ne[3]) return false;
+    if (a->nb[2] < a->nb[1] * (size_t) a->ne[1] || (a->ne[3] > 1 && a->nb[3] < a->nb[2] * (size_t) a->ne[2])) return false;   // permuted src0
+    return true;
+}
+
+bool supports_mul_mat_id(const struct ggml_tensor * op) {
+    const ggml_tensor * as = op->src[0], * b = op->src[1], * ids = op->src[2];
+    if (!mul_mat_shape_ok(op) || !ids || ids->type != GGML_TYPE_I32) return false;
+    if (as->ne[3] != 1 || b->ne[3] != 1 || ids->ne[2] != 1 || ids->ne[3] != 1) return false;
+    if (ids->nb[0] != sizeof(int32_t) || ids->nb[1] % 4) return false;
+    if (b->ne[1] != 1 && b->ne[1] != ids->ne[0]) return false;                     // ne11 broadcast rule (ggml.c:2781-2808)
+    if (as->nb[2] < as->nb[1] * (size_t) as->ne[1]) return false;
+    if (op->nb[2] % 4) return false;
+    return true;
+}
+
+enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, const ggml_tensor * const * nodes, int n_nodes, int * consumed) {
+    const ggml_tensor * dst = nodes[0];
+    const ggml_tensor * a = dst->src[0], * b = dst->src[1];
+    qmm_ctx * q = ctx->dev->qmm;
+    void * st = qmm_stream(q);
+    *consumed = 1;
+    const int64_t K = a->ne[0], N = b->ne[1];
+    const bool flat = a->ne[2] == 1 && a->ne[3] == 1 && b->ne[2] == 1 && b->ne[3] == 1;
+    if (flat && N <= QMM_MATVEC_MAX_N) {
+        // group the following MUL_MAT nodes that read the same src1 (wq/wk/wv, ffn gate/up): one launch per weight type
+        qmm_weight ws[4];
+        int n = 0;
+        for (int i = 0; i < n_nodes && n < 4; ++i) {
+            const ggml_tensor * d = nodes[i];
+            if (d->op != GGML_OP_MUL_MAT || d->src[1] != b || !supports_mul_mat(d) || !is_ours(d->src[0])) break;
+            const ggml_tensor * w = d->src[0];
+            if (w->ne[2] != 1 || w->ne[3] != 1 || w->ne[0] != K) break;
+            ws[n++] = qmm_weight{ w->data, (int64_t) w->nb[1], w->ne[1], (float *) d->data, (int64_t) (d->nb[1] / sizeof(float)), (int) w->type };
+        }
+        if (qmm_mul_mat_group(q, ws, n, K, (const float *) b->data, N, b->nb[1] / sizeof(float), st)) {
+            GGML_LOG_ERROR("MI355X MUL_MAT(%s): %s\n", dst->name, qmm_last_error());
+            return GGML_STATUS_FAILED;
+        }
+        *consumed = n;
+        return GGML_STATUS_SUCCESS;
+    }
+    // batched / broadcast form: one 2-D product per (i12, i13), src0 broadcast as ggml_compute_forward_mul_mat does
+    // (ggml-cpu.c:6711-6716: i03 = i13 / r3, i02 = i12 / r2)
+    const int64_t r2 = b->ne[2] / a->ne[2], r3 = b->ne[3] / a->ne[3];
+    for (int64_t i13 = 0; i13 < b->ne[3]; ++i13)
+        for (int64_t i12 = 0; i12 < b->ne[2]; ++i12) {
+            const char * wp = (const char *) a->data + (i12 / r2) * a->nb[2] + (i13 / r3) * a->nb[3];
+            const char * xp = (const char *) b->data + i12 * b->nb[2] + i13 * b->nb[3];
+            char * dp = (char *) dst->data + i12 * dst->nb[2] + i13 * dst->nb[3];
+            if (qmm_mul_mat(q, a->type, wp, a->nb[1], K, a->ne[1], (const float *) xp, N, b->nb[1] / sizeof(float),
+                            (float *) dp, dst->nb[1] / sizeof(float), st)) {
+                GGML_LOG_ERROR("MI355X MUL_MAT(%s): %s\n", dst->name, qmm_last_error());
+                return GGML_STATUS_FAILED;
+            }
+        }
+    return GGML_STATUS_SUCCESS;
+}
+
+enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, const ggml_tensor * dst) {
+    const ggml_tensor * as = dst->src[0], * b = dst->src[1], * ids = dst->src[2];
+    qmm_ctx * q = ctx->dev->qmm;
+    if (qmm_mul_mat_id(q, as->type, as->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
+                       (const float *) b->data, b->ne[1], b->nb[1], b->nb[2],
+                       (const int32_t *) ids->data, ids->ne[0], ids->ne[1], ids->nb[1],
+                       (float *) dst->data, dst->nb[1], dst->nb[2], qmm_stream(q))) {
+        GGML_LOG_ERROR("MI355X MUL_MAT_ID(%s): %s\n", dst->name, qmm_last_error());
+        return GGML_STATUS_FAILED;
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+// ----------------------------------------------------------------------------------------------- backend (stream)
+
+const char * backend_get_name(ggml_backend_t backend) { return ((mi355x_backend_ctx *) backend->context)->name.c_str(); }
+
+void backend_free(ggml_backend_t backend) {
+    delete (mi355x_backend_ctx *) backend->context;
+    delete backend;
+}
+
+void backend_synchronize(ggml_backend_t backend) {
+    auto * ctx = (mi355x_backend_ctx *) backend->context;
+    if (qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm)))
+        GGML_LOG_ERROR("MI355X synchronize: %s\n", qmm_last_error());
+}
+
+enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
+    auto * ctx = (mi355x_backend_ctx *) backend->context;
+    for (int i = 0; i < cgraph->n_nodes;) {
+        struct ggml_tensor * node = cgraph->nodes[i];
+        if (ggml_is_empty(node) || node->op == GGML_OP_NONE || node->op == GGML_OP_RESHAPE || node->op == GGML_OP_VIEW ||
+            node->op == GGML_OP_PERMUTE || node->op == GGML_OP_TRANSPOSE) {            // ggml-hexagon.cpp:5561-5566
+            ++i;
+            continue;
+        }
+        enum ggml_status st;
+        int consumed = 1;
+        if (node->op == GGML_OP_MUL_MAT) {
+            st = compute_mul_mat(ctx, cgraph->nodes + i, cgraph->n_nodes - i, &consumed);
+        } else if (node->op == GGML_OP_MUL_MAT_ID) {
+            st = compute_mul_mat_id(ctx, node);
+        } else {
+            GGML_LOG_ERROR("MI355X: op %s (%s) is outside the offloaded surface\n", ggml_op_name(node->op), node->name);
+            st = GGML_STATUS_FAILED;
+        }
+        if (st != GGML_STATUS_SUCCESS) return st;
+        i += consumed;
+    }
+    // the scheduler reads results right after graph_compute/synchronize; a bad expert id surfaces here
+    if (qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm))) {
+        GGML_LOG_ERROR("MI355X graph_compute: %s\n", qmm_last_error());
+        return GGML_STATUS_FAILED;
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+const ggml_backend_i backend_iface = {
+    /* .get_name           = */ backend_get_name,
+    /* .free               = */ backend_free,
+    /* .set_tensor_async   = */ nullptr,
+    /* .get_tensor_async   = */ nullptr,
+    /* .cpy_tensor_async   = */ nullptr,
+    /* .synchronize        = */ backend_synchronize,
+    /* .graph_plan_create  = */ nullptr,
+    /* .graph_plan_free    = */ nullptr,
+    /* .graph_plan_update  = */ nullptr,
+    /* .graph_plan_compute = */ nullptr,
+    /* .graph_compute      = */ backend_graph_compute,
+    /* .event_record       = */ nullptr,
+    /* .event_wait         = */ nullptr,
+};
+
+ggml_guid_t backend_guid() {
+    static ggml_guid guid = { 0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x2d, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30, 0x2d, 0x71, 0x6d };
+    return &guid;
+}
+
+// ----------------------------------------------------------------------------------------------- device
+
+const char * dev_get_name(ggml_backend_dev_t dev) { return ((mi355x_device_ctx *) dev->context)->name.c_str(); }
+const char * dev_get_description(ggml_backend_dev_t dev) { return ((mi355x_device_ctx *) dev->context)->description.c_str(); }
+void dev_get_memory(ggml_backend_dev_t dev, size_t * free, size_t * total) {
+    qmm_device_info(((mi355x_device_ctx *) dev->context)->qmm, nullptr, 0, free, total, nullptr);
+}
+enum ggml_backend_dev_type dev_get_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
+void dev_get_props(ggml_backend_dev_t dev, struct ggml_backend_dev_props * props) {
+    props->name = dev_get_name(dev);
+    props->description = dev_get_description(dev);
+    props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
+    dev_get_memory(dev, &props->memory_free, &props->memory_total);
+    props->caps = { /* async */ false, /* host_buffer */ false, /* buffer_from_host_ptr */ false, /* events */ false };
+}
+ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
+    auto * d = (mi355x_device_ctx *) dev->context;
+    return new ggml_backend{ backend_guid(), backend_iface, dev, new mi355x_backend_ctx{ d, d->name } };
+}
+ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &((mi355x_device_ctx *) dev->context)->buft; }
+
+bool dev_supports_op(ggml_backend_dev_t, const struct ggml_tensor * op) {
+    switch (op->op) {
+        case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+            return true;
+        case GGML_OP_MUL_MAT:    return supports_mul_mat(op);
+        case GGML_OP_MUL_MAT_ID: return supports_mul_mat_id(op);
+        default: return false;
+    }
+}
+bool dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    return buft->iface.get_name == buft_get_name && buft->context == dev->context;
+}
+
+const ggml_backend_device_i device_iface = {
+    /* .get_name             = */ dev_get_name,
+    /* .get_description      = */ dev_get_description,
+    /* .get_memory           = */ dev_get_memory,
+    /* .get_type             = */ dev_get_type,
+    /* .get_props            = */ dev_get_props,
+    /* .init_backend         = */ dev_init_backend,
+    /* .get_buffer_type      = */ dev_get_buffer_type,
+    /* .get_host_buffer_type = */ nullptr,
+    /* .buffer_from_host_ptr = */ nullptr,
+    /* .supports_op          = */ dev_supports_op,
+    /* .supports_buft        = */ dev_supports_buft,
+    /* .offload_op           = */ nullptr,
+    /* .event_new            = */ nullptr,
+    /* .event_free           = */ nullptr,
+    /* .event_synchronize    = */ nullptr,
+};
+
+// ----------------------------------------------------------------------------------------------- reg
+
+const char * reg_get_name(ggml_backend_reg_t) { return GGML_MI355X_BACKEND_NAME; }
+size_t reg_get_device_count(ggml_backend_reg_t) { return (size_t) g_ndev; }
+ggml_backend_dev_t reg_get_device(ggml_backend_reg_t, size_t index) { return index < (size_t) g_ndev ? &g_devices[index] : nullptr; }
+void * reg_get_proc_address(ggml_backend_reg_t, const char *) {
+    // "ggml_backend_split_buffer_type" is not exported yet: llama.cpp then falls back to layer split
+    // (src/llama-model.cpp:316-346).  Row split lives in the one-process-per-GPU path (rowsplit.py) this round.
+    return nullptr;
+}
+
+const ggml_backend_reg_i reg_iface = { reg_get_name, reg_get_device_count, reg_get_device, reg_get_proc_address };
+
+} // namespace
+
+extern "C" {
+
+ggml_backend_reg_t ggml_backend_mi355x_reg(void) {
+    static ggml_backend_reg reg = { GGML_BACKEND_API_VERSION, reg_iface, nullptr };
+    static std::once_flag once;                                     // the reference guards its reg init too (ggml-hexagon.cpp:5953-5955)
+    std::call_once(once, [] {
+        const int n = qmm_device_count();
+        for (int i = 0; i < n && g_ndev < GGML_MI355X_MAX_DEVICES; ++i) {
+            qmm_ctx * q = qmm_create(i);
+            if (!q) {
+                GGML_LOG_WARN("MI355X: skipping HIP device %d: %s\n", i, qmm_last_error());
+                continue;
+            }
+            mi355x_device_ctx & d = g_devs[g_ndev];
+            d.ordinal = i;
+            d.qmm = q;
+            d.name = std::string(GGML_MI355X_BACKEND_NAME) + std::to_string(g_ndev);
+            char nm[128] = { 0 };
+            int cus = 0;
+            qmm_device_info(q, nm, sizeof(nm), nullptr, nullptr, &cus);
+            d.description = std::string(nm) + " (gfx950, " + std::to_string(cus) + " CUs)";
+            d.buft_name = d.name;
+            g_devices[g_ndev] = ggml_backend_device{ device_iface, &reg, &d };
+            d.buft = ggml_backend_buffer_type{ buft_iface, &g_devices[g_ndev], &d };
+            ++g_ndev;
+        }
+        GGML_LOG_INFO("MI355X backend: %d device(s); offloads quantized MUL_MAT / MUL_MAT_ID (Q4_0 Q8_0 Q4_K Q5_K Q6_K)\n", g_ndev);
+    });
+    return &reg;
+}
+
+int ggml_backend_mi355x_get_device_count(void) {
+    ggml_backend_mi355x_reg();
+    return g_ndev;
+}
+
+const char * ggml_backend_mi355x_get_devname(size_t dev_num) {
+    ggml_backend_mi355x_reg();
+    return dev_num < (size_t) g_ndev ? g_devs[dev_num].name.c_str() : "unknown";
+}
+
+ggml_backend_buffer_type_t ggml_backend_mi355x_buffer_type(size_t dev_num) {
+    ggml_backend_mi355x_reg();
+    return dev_num < (size_t) g_ndev ? &g_devs[dev_num].buft : nullptr;
+}
+
+ggml_backend_t ggml_backend_mi355x_init(size_t dev_num) {
+    ggml_backend_mi355x_reg();
+    if (dev_num >= (size_t) g_ndev) {
+        GGML_LOG_ERROR("%s: invalid device %zu (have %d)\n", __func__, dev_num, g_ndev);
+        return nullptr;
+    }
+    return dev_init_backend(&g_devices[dev_num], nullptr);
+}
+
+bool ggml_backend_is_mi355x(ggml_backend_t backend) { return backend != nullptr && ggml_guid_matches(backend->guid, backend_guid()); }
+
+static int ggml_backend_mi355x_score(void) { return qmm_device_count() > 0 ? 100 : 0; }
+
+} // extern "C"
+
+GGML_BACKEND_DL_IMPL(ggml_backend_mi355x_reg)
+GGML_BACKEND_DL_SCORE_IMPL(ggml_backend_mi355x_score)
