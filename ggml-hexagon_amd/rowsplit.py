@@ -31,8 +31,7 @@ class RowConcat:
     """Gathers per-rank dst slices [N, rows_r] into the full dst [N, M] on every rank.
 
     Equal slices use one all_gather_into_tensor (RCCL ring/direct over xGMI) into a [world, N, rows] staging
-    buffer followed by one permute-copy; ragged slices (last rank takes the remainder) use all_gather with
-    per-rank tensors.  Works unchanged with the gloo backend on CPU tensors (tests)."""
+    buffer followed by one permute-copy; ragged slices (last rank takes the remainder) are padded to the widest.  Works unchanged with the gloo backend on CPU tensors (tests)."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -52,12 +51,19 @@ class RowConcat:
             out.copy_(local)
             return out
         if len(set(sizes)) == 1 and local.is_contiguous():
-            stage = torch.empty((self.world, n, sizes[0]), dtype=local.dtype, device=local.device)
+            stage = torch.empty((self.world * n, sizes[0]), dtype=local.dtype, device=local.device)
             self.dist.all_gather_into_tensor(stage, local, group=self.group)
-            out.view(n, self.world, sizes[0]).copy_(stage.permute(1, 0, 2))
+            out.view(n, self.world, sizes[0]).copy_(stage.view(self.world, n, sizes[0]).permute(1, 0, 2))
         else:
-            parts = [torch.empty((n, s), dtype=local.dtype, device=local.device) for s in sizes]
-            self.dist.all_gather(parts, local.contiguous(), group=self.group)
-            for (lo, hi), p in zip(ranges, parts):
-                out[:, lo:hi] = p
+            # ragged slices (ggml gives the remainder rows to the last device): pad to the widest slice so that one
+            # equal-size all-gather still does the exchange, then drop the padding while concatenating
+            smax = max(sizes)
+            padded = torch.zeros((n, smax), dtype=local.dtype, device=local.device)
+            padded[:, :local.shape[1]] = local
+            stage = torch.empty((self.world * n, smax), dtype=local.dtype, device=local.device)
+            self.dist.all_gather_into_tensor(stage, padded, group=self.group)
+            stage = stage.view(self.world, n, smax)
+            for r, (lo, hi) in enumerate(ranges):
+                if hi > lo:
+                    out[:, lo:hi] = stage[r, :, :hi - lo]
         return out

@@ -1,0 +1,131 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol (no compute without a GPU), the product
+path fails loudly without a device, the workload tables match SURVEY.md's byte/flop accounting, and the row-split
+partition + concat (the N > 1 path) is correct under a world_size-2 gloo run."""
+import ctypes
+import os
+import re
+import socket
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_capi_exports_every_declared_symbol():
+    from ggml_hexagon_amd import build, capi
+    so = build.build_qmm()
+    lib = ctypes.CDLL(str(so))
+    header = (ROOT / "include" / "ggml_mi355x_qmm.h").read_text()
+    declared = re.findall(r"QMM_API\s+[\w\s\*]+?\b(qmm_\w+)\s*\(", header)
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ggml_mi355x_qmm.h but not exported"
+    assert set(declared) == set(capi.EXPORTS)
+    assert lib.qmm_abi_version() == 1
+    lib.qmm_row_size.restype = ctypes.c_size_t
+    lib.qmm_row_size.argtypes = [ctypes.c_int, ctypes.c_int64]
+    assert [lib.qmm_row_size(t, 4096) for t in (2, 8, 12, 13, 14)] == [2304, 4352, 2304, 2816, 3360]
+    assert lib.qmm_row_size(12, 100) == 0 and lib.qmm_row_size(0, 4096) == 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the CPU-only container")
+    from ggml_hexagon_amd.capi import Qmm, QmmError
+    with pytest.raises(QmmError):
+        Qmm(0)
+
+
+def test_plugin_module_exports_the_ggml_entry_points():
+    so = ROOT / "ggml-hexagon_amd" / "libggml-mi355x.so"
+    if not so.exists():
+        pytest.skip("plugin not built (needs the ggml headers of the host tree)")
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True).stdout
+    for name in ("ggml_backend_init", "ggml_backend_score", "ggml_backend_mi355x_reg", "ggml_backend_mi355x_init",
+                 "ggml_backend_is_mi355x", "ggml_backend_mi355x_get_device_count", "ggml_backend_mi355x_get_devname",
+                 "ggml_backend_mi355x_buffer_type"):
+        assert re.search(rf"\bT {name}\b", syms), name
+
+
+def test_workload_accounting_matches_survey():
+    from ggml_hexagon_amd import workload
+    w = workload.get("synth-7b-q4_k")
+    # 6,607,077,376 matmul weights x 0.5625 B = 3,716,481,024 B/token; pp512 = 6.766e12 flop
+    assert w.weight_bytes() == 3_716_481_024
+    assert w.flops(512) == 2 * 6_607_077_376 * 512
+    assert len(w.all_mats()) == 32 * 7 + 1
+    l3 = workload.get("llama3-8b-q4_k_m")
+    types = {m.name: m.type for m in l3.all_mats()}
+    assert types["blk.0.attn_v"] == 14 and types["blk.0.ffn_down"] == 14          # use_more_bits layers -> Q6_K
+    assert types["blk.4.attn_v"] == 12 and types["blk.4.ffn_down"] == 12
+    assert types["output"] == 14 and types["blk.7.attn_q"] == 12
+    mx = workload.get("mixtral-8x7b-q4_k_m")
+    ids = [m for m in mx.all_mats() if m.n_expert]
+    assert len(ids) == 32 * 3 and ids[0].n_expert == 8 and ids[0].n_used == 2
+    assert {m.type for m in mx.all_mats() if m.name.endswith("attn_k")} == {8}     # n_expert == 8: attn_k/v -> Q8_0
+    l70 = workload.get("llama3-70b-q4_k_m")
+    assert 13 in {m.type for m in l70.all_mats() if m.name.endswith("attn_v")}      # 70B rule: Q5_K
+
+
+def test_row_ranges_follow_ggml_row_split():
+    from ggml_hexagon_amd.rowsplit import all_ranges, row_range
+    for m in (4096, 14336, 128256, 1024, 100):
+        for world in (1, 2, 4, 8):
+            rs = all_ranges(m, world)
+            assert rs[0][0] == 0 and rs[-1][1] == m
+            for (lo, hi), (lo2, _) in zip(rs, rs[1:]):
+                assert hi == lo2 and lo % 64 == 0
+    assert row_range(128256, 7, 8) == (112192, 128256)       # the last device takes the remainder (ggml-cuda.cu:740-753)
+    assert all_ranges(100, 4) == [(0, 0), (0, 0), (0, 64), (64, 100)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rowsplit_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ggml_hexagon_amd import rowsplit, synth
+        from oracle.pyoracle import Oracle
+        o = Oracle()
+        cc = rowsplit.RowConcat()
+        ok = True
+        for (t, m, k, n) in ((12, 256, 512, 3), (14, 200, 256, 1), (2, 192, 64, 5)):
+            w = synth.synth_weights(t, m, k, seed=3, sigma=0.2)                 # every rank builds the full matrix ...
+            x = np.random.default_rng(1).uniform(-1, 1, (n, k)).astype(np.float32)
+            ranges = rowsplit.all_ranges(m, world)
+            lo, hi = ranges[rank]
+            local = o.mul_mat(t, w[lo:hi], k, x) if hi > lo else np.zeros((n, 0), np.float32)   # ... computes only its rows
+            full = cc.concat(torch.from_numpy(np.ascontiguousarray(local)), ranges).numpy()
+            ok &= np.array_equal(full, o.mul_mat(t, w, k, x))                   # concat == single-device result, bit for bit
+        q.put((rank, bool(ok)))
+    except Exception as e:                                                      # report instead of hanging the parent
+        q.put((rank, f"{type(e).__name__}: {e}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rowsplit_concat_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rowsplit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
