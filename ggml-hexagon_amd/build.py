@@ -31,7 +31,7 @@ def build_qmm(force: bool = False) -> Path:
         if QMM_SO.exists():
             return QMM_SO
         raise RuntimeError("hipcc not found and no prebuilt libggml_mi355x_qmm.so")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fno-slp-vectorize",
            "-o", str(QMM_SO), str(CSRC / "qmm_api.hip")]
     subprocess.run(cmd, check=True)
     return QMM_SO

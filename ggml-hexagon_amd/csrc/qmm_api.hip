@@ -124,6 +124,8 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->act_mode = atoi(e) ? QMM_ACT_X86 : QMM_ACT_REF;
     e = getenv("GGML_MI355X_MV_BPC");
     if (e && atoi(e) >= 1 && atoi(e) <= 8) c->mv_bpc = atoi(e);
+    e = getenv("GGML_MI355X_ABLATE");
+    if (e) { int v = atoi(e); (void) hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_dbg), &v, sizeof(int)); }
     e = getenv("GGML_MI355X_PREC");
     if (e) c->prec = (!strcmp(e, "bf16") || !strcmp(e, "0")) ? QMM_PREC_BF16 : QMM_PREC_F16_Q8;
     return c;

@@ -106,6 +106,7 @@ template <> struct Unit<T_Q4_0> {
         qs = ldg<uint4>(blk + 2);
     }
     static __device__ __forceinline__ int k_run(int u, int r) { return u * 32 + r * 16; }
+    __device__ __forceinline__ void kill() { d = 0; }
     __device__ __forceinline__ void to_f32(int, float * out) const {
         const float df = h2f(d);
         const uint32_t w[4] = { qs.x, qs.y, qs.z, qs.w };
@@ -147,6 +148,7 @@ template <> struct Unit<T_Q8_0> {
         q1 = ldg<uint4>(blk + 18);
     }
     static __device__ __forceinline__ int k_run(int u, int) { return u * 32; }
+    __device__ __forceinline__ void kill() { d = 0; }
     __device__ __forceinline__ void to_f32(int, float * out) const {
         const float df = h2f(d);
         const uint32_t w[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
@@ -183,6 +185,7 @@ template <> struct Unit<T_Q4_K> {
         const int q = u & 7;
         return (u >> 3) * 256 + 64 * (q >> 1) + 16 * (q & 1) + 32 * r;
     }
+    __device__ __forceinline__ void kill() { hdr.x = 0; }          // d = dmin = 0
     __device__ __forceinline__ void to_f32(int u, float * out) const {
         const int j = (u & 7) >> 1;
         int s0, m0, s1, m1;
@@ -233,6 +236,7 @@ template <> struct Unit<T_Q5_K> {
         qs  = ldg<uint4>(blk + 48 + 16 * (u & 7));
     }
     static __device__ __forceinline__ int k_run(int u, int r) { return Unit<T_Q4_K>::k_run(u, r); }
+    __device__ __forceinline__ void kill() { hdr.x = 0; }
     // 5-bit values of dword i: low-nibble weights and high-nibble weights
     __device__ __forceinline__ void q5(int i, int j, uint32_t & lo, uint32_t & hi) const {
         const uint32_t w = i == 0 ? qs.x : i == 1 ? qs.y : i == 2 ? qs.z : qs.w;
@@ -302,6 +306,7 @@ template <> struct Unit<T_Q6_K> {
     static __device__ __forceinline__ int k_run(int u, int r) {
         return (u >> 2) * 256 + 128 * ((u >> 1) & 1) + 16 * (u & 1) + 32 * r;
     }
+    __device__ __forceinline__ void kill() { d = 0; }
     __device__ __forceinline__ int scale(int g, int r) const {      // sc[8n + g + 2r]
         const int i = g + 2 * r;
         const uint32_t w = i < 4 ? sc8.x : sc8.y;

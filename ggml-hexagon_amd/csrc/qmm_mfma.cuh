@@ -33,6 +33,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16   bf16x8 __attribute__((ext_vector_type(8)));
 typedef float    f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ int g_mfma_dbg = 0;     // development ablation knob (GGML_MI355X_ABLATE), 0 in production
+
 template <int T> struct MfmaBK { static constexpr int value = 64; };
 template <> struct MfmaBK<T_Q6_K> { static constexpr int value = 128; };
 
@@ -121,9 +123,19 @@ prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t *
 }
 
 // ------------------------------------------------------------------------------------------------
-// stage 2
+// stage 2.  Wave-specialized workgroup of 8 waves (512 threads) per BN x BM tile of dst:
+//
+//   waves 4-7  PRODUCERS   fetch(ks+3): one weight unit per thread straight from HBM + the matching Xh chunks
+//                          stash(ks+1): unpack the unit bit-exactly to f32 (Unit<T>::to_f32), round to f16/bf16,
+//                                       write both tiles into LDS stage (ks+1)&1 (XOR-swizzled, conflict-free)
+//   waves 0-3  CONSUMERS   compute(ks): ds_read_b128 fragments from LDS stage ks&1 + v_mfma_f32_32x32x16_{f16,bf16}
+//
+// One barrier per K-step.  The two roles run different loops that meet at the same s_barrier count; on a SIMD the
+// producer wave's VALU work and the consumer wave's MFMAs issue to different pipes and overlap (measured: with all
+// roles in one wave per SIMD the three phases simply add up).  Loads are unconditional (K-step index clamped): a branch
+// around a global_load makes hipcc drain vmcnt to 0.  Fetched data has two K-steps of latency cover.
 template <int T, int BM, bool F16>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 mfma_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64_t expert_bytes, const int M, const int K,
             const uint16_t * __restrict__ Xh, const int Kp, const float * __restrict__ scale,
             const int * __restrict__ seg_start, const int * __restrict__ seg_count, const int N,
@@ -134,31 +146,106 @@ mfma_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64
     constexpr int SLOTS = BK / 8;                            // 16-byte slots per tile row
     constexpr int UPS = BK / Traits<T>::UNIT_W;              // weight units per row per K-step (= 2)
     constexpr int W_UNITS = BM * UPS;                        // units per K-step (128 or 256)
-    constexpr int X_CHUNKS = BN * SLOTS / 256;               // 16-byte chunks per thread per K-step
-    constexpr int RT = BM / 64;                              // 32-row MFMA tiles per wave along the weight rows
+    constexpr int X_CHUNKS = BN * SLOTS / 256;               // 16-byte chunks per producer thread per K-step
+    constexpr int RT = BM / 64;                              // 32-row MFMA tiles per consumer wave along the weight rows
+    constexpr int STAGE = (BM + BN) * ROWB;
     static_assert(UPS == 2, "unit/K-step geometry");
 
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(BM + BN) * ROWB];
-    uint8_t * Ws = lds;
-    uint8_t * Xs = lds + BM * ROWB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // 2 stages of [Ws | Xs]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg0 = seg_start ? seg_start[blockIdx.z] : 0;
     const int segn = seg_count ? seg_count[blockIdx.z] : N;
     const int tok0 = blockIdx.y * BN;                        // within the segment
     if (tok0 >= segn) return;
     const int row0 = blockIdx.x * BM;
-    const uint8_t * Wz = W + (int64_t) blockIdx.z * expert_bytes;
+    const int nk = Kp / BK;                                  // even: Kp is a multiple of 128
+    const int dbg = g_mfma_dbg;
 
-    // this thread's weight unit: row (tid>>1), half (tid&1); rows past M re-read row M-1 (never stored)
-    const bool has_w = tid < W_UNITS;
-    const int  wr = tid >> 1;
-    const uint8_t * wrow = Wz + (int64_t) min(row0 + wr, M - 1) * row_bytes;
-    const int units_per_row = K / Traits<T>::UNIT_W;
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) {
+        // ------------------------------------------------------------------ producers
+        const int tid = threadIdx.x - 256;
+        const uint8_t * Wz = W + (int64_t) blockIdx.z * expert_bytes;
+        const bool has_w = tid < W_UNITS;
+        const int  wr = tid >> 1;                            // rows past M re-read row M-1 (never stored)
+        const uint8_t * wrow = Wz + (int64_t) min(row0 + min(wr, BM - 1), M - 1) * row_bytes;
+        const int units_per_row = K / Traits<T>::UNIT_W;
+        const uint8_t * xthr = reinterpret_cast<const uint8_t *>(Xh + (int64_t) (seg0 + tok0) * Kp) +
+                               (size_t) (tid / SLOTS) * Kp * 2 + (tid % SLOTS) * 16;
+        const int xrow_step = (256 / SLOTS) * Kp * 2;        // bytes between this thread's consecutive chunks
 
-    // this thread's activation chunks: chunk c = tid + 256*i -> row c / SLOTS, slot c % SLOTS
-    const uint16_t * xbase = Xh + (int64_t) (seg0 + tok0) * Kp;
+        struct Regs { Unit<T> wu; uint4 xc[X_CHUNKS]; };
+        auto fetch = [&](Regs & r, int ks_raw) {
+            const int ks = min(ks_raw, nk - 1);
+            const int u = ks * UPS + (tid & 1);
+            r.wu.load(wrow, min(u, units_per_row - 1));
+            if (u >= units_per_row) r.wu.kill();              // K tail of a padded K-step: scales -> 0, values -> 0
+            const uint8_t * xp = xthr + ks * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < X_CHUNKS; ++i) r.xc[i] = *reinterpret_cast<const uint4 *>(xp + i * xrow_step);
+        };
+        auto stash = [&](const Regs & r, int ks_raw, uint8_t * stage) {
+            const int ks = min(ks_raw, nk - 1);
+            uint8_t * Ws = stage;
+            uint8_t * Xs = stage + BM * ROWB;
+            const int u = min(ks * UPS + (tid & 1), units_per_row - 1);
+            if (has_w) {
+                float v[Traits<T>::UNIT_W];
+                r.wu.to_f32(u, v);
+#pragma unroll
+                for (int rr = 0; rr < Unit<T>::RUNS; ++rr) {
+                    const int kk = Unit<T>::k_run(tid & 1, rr) & (BK - 1);   // offset inside the K-step window
+#pragma unroll
+                    for (int e = 0; e < Unit<T>::RUN_LEN; e += 8) {
+                        uint4 o;
+                        o.x = pack16<F16>(v[rr * Unit<T>::RUN_LEN + e + 0], v[rr * Unit<T>::RUN_LEN + e + 1]);
+                        o.y = pack16<F16>(v[rr * Unit<T>::RUN_LEN + e + 2], v[rr * Unit<T>::RUN_LEN + e + 3]);
+                        o.z = pack16<F16>(v[rr * Unit<T>::RUN_LEN + e + 4], v[rr * Unit<T>::RUN_LEN + e + 5]);
+                        o.w = pack16<F16>(v[rr * Unit<T>::RUN_LEN + e + 6], v[rr * Unit<T>::RUN_LEN + e + 7]);
+                        *reinterpret_cast<uint4 *>(Ws + tile_off<BK>(wr, (kk + e) >> 3)) = o;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < X_CHUNKS; ++i) {
+                const int c = tid + 256 * i;
+                *reinterpret_cast<uint4 *>(Xs + tile_off<BK>(c / SLOTS, c % SLOTS)) = r.xc[i];
+            }
+        };
 
+        // register ring: PF K-steps of loads in flight per thread (HBM/L2 latency under load is ~1 us, a K-step ~0.2 us)
+        constexpr int PF = 2;
+        Regs ring[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) fetch(ring[i], i);
+        stash(ring[0], 0, lds);
+        fetch(ring[0], PF);
+        __syncthreads();
+        for (int ks = 0; ks < nk; ks += PF) {                 // nk % PF == 0 is not required: indices are clamped, extra
+#pragma unroll                                                 // iterations past nk are skipped below
+            for (int i = 1; i <= PF; ++i) {
+                if (ks + i - 1 < nk) {                        // uniform; matches the consumers' barrier count
+                    const int slot = i % PF;
+                    if (!(dbg & 1)) stash(ring[slot], ks + i, lds + ((ks + i) & 1) * STAGE);
+                    if (!(dbg & 2)) fetch(ring[slot], ks + i + PF);
+                    __syncthreads();
+                }
+            }
+        }
+        // both LDS stages are free now: stage the tile's per-token scales and dst row offsets for the epilogue
+        float *   sc_lds  = reinterpret_cast<float *>(lds);
+        int64_t * off_lds = reinterpret_cast<int64_t *>(lds + 1024);
+        if (tid < BN) {
+            const int t = tok0 + tid;
+            const bool live = t < segn;
+            sc_lds[tid]  = live ? scale[seg0 + t] : 0.0f;
+            off_lds[tid] = live ? (dst_off ? dst_off[seg0 + t] : (int64_t) t * ldd) : 0;
+        }
+        __syncthreads();
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_t = (wave & 1) * 64;                      // token offset of the wave inside the tile
     const int wave_r = (wave >> 1) * (BM / 2);               // weight-row offset
 
@@ -170,53 +257,9 @@ mfma_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    Unit<T> wu;
-    uint4   xc[X_CHUNKS];
-    const int nk = Kp / BK;
-
-    auto fetch = [&](int ks) {
-        const int u = ks * UPS + (tid & 1);
-        if (has_w && u < units_per_row) wu.load(wrow, u);
-#pragma unroll
-        for (int i = 0; i < X_CHUNKS; ++i) {
-            const int c = tid + 256 * i;
-            xc[i] = *reinterpret_cast<const uint4 *>(xbase + (int64_t) (c / SLOTS) * Kp + ks * BK + (c % SLOTS) * 8);
-        }
-    };
-    auto stash = [&](int ks) {
-        const int u = ks * UPS + (tid & 1);
-        if (has_w) {
-            float v[Traits<T>::UNIT_W];
-            if (u < units_per_row) {
-                wu.to_f32(u, v);
-            } else {
-#pragma unroll
-                for (int e = 0; e < Traits<T>::UNIT_W; ++e) v[e] = 0.0f;
-            }
-#pragma unroll
-            for (int rr = 0; rr < Unit<T>::RUNS; ++rr) {
-                const int kk = Unit<T>::k_run(ks * UPS + (tid & 1), rr) - ks * BK;      // offset inside the K-step window
-#pragma unroll
-                for (int e = 0; e < Unit<T>::RUN_LEN; e += 8) {
-                    const float * p = v + rr * Unit<T>::RUN_LEN + e;
-                    const uint4 o = make_uint4(pack16<F16>(p[0], p[1]), pack16<F16>(p[2], p[3]),
-                                               pack16<F16>(p[4], p[5]), pack16<F16>(p[6], p[7]));
-                    *reinterpret_cast<uint4 *>(Ws + tile_off<BK>(wr, (kk + e) >> 3)) = o;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < X_CHUNKS; ++i) {
-            const int c = tid + 256 * i;
-            *reinterpret_cast<uint4 *>(Xs + tile_off<BK>(c / SLOTS, c % SLOTS)) = xc[i];
-        }
-    };
-
-    fetch(0);
-    for (int ks = 0; ks < nk; ++ks) {
-        stash(ks);
-        __syncthreads();
-        if (ks + 1 < nk) fetch(ks + 1);
+    auto compute = [&](const uint8_t * stage) {
+        const uint8_t * Ws = stage;
+        const uint8_t * Xs = stage + BM * ROWB;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const int slot = kk * 2 + (lane >> 5);
@@ -237,18 +280,29 @@ mfma_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64
                                                                            *reinterpret_cast<const bf16x8 *>(&b[j]), acc[i][j], 0, 0, 0);
                 }
         }
+    };
+
+    __syncthreads();
+    for (int ks = 0; ks < nk; ks += 2) {
+        if (!(dbg & 4)) compute(lds);
+        __syncthreads();
+        if (!(dbg & 4)) compute(lds + STAGE);
         __syncthreads();
     }
 
-    // epilogue: D[i = token][j = weight row]; lane -> weight row, registers -> tokens
+    // epilogue: D[i = token][j = weight row]; lane -> weight row, registers -> tokens.  Scales / row offsets come from
+    // LDS (staged by the producers) so that no dependent global load sits in front of the stores.
+    __syncthreads();
+    const float *   sc_lds  = reinterpret_cast<const float *>(lds);
+    const int64_t * off_lds = reinterpret_cast<const int64_t *>(lds + 1024);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int t = tok0 + wave_t + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            if (t < segn) {
-                const float sc = scale[seg0 + t];
-                float * drow = dst + (dst_off ? dst_off[seg0 + t] : (int64_t) t * ldd);
+            const int tl = wave_t + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (tok0 + tl < segn) {
+                const float sc = sc_lds[tl];
+                float * drow = dst + off_lds[tl];
 #pragma unroll
                 for (int j = 0; j < RT; ++j) {
                     const int m = row0 + wave_r + 32 * j + (lane & 31);
@@ -290,10 +344,15 @@ inline int launch_mfma(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, 
     const bool f16 = c->prec == QMM_PREC_F16_Q8;
     // 64-row tiles when 128-row tiles would leave CUs idle
     const bool small = (int64_t) ((M + 127) / 128) * n_tiles_y * n_expert < c->cus;
-    const dim3 block(256);
+    const dim3 block(512);
 #define QMM_LAUNCH(BMv, F16v)                                                                                                      \
-    hipLaunchKernelGGL((mfma_kernel<T, BMv, F16v>), dim3((M + BMv - 1) / BMv, n_tiles_y, n_expert), block, 0, st, (const uint8_t *) W, \
-                       rb, eb, M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off)
+    do {                                                                                                                           \
+        auto kern = mfma_kernel<T, BMv, F16v>;                                                                                     \
+        const size_t lds = (size_t) 2 * (BMv + 128) * MfmaBK<T>::value * 2;                                                       \
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+        hipLaunchKernelGGL(kern, dim3((M + BMv - 1) / BMv, n_tiles_y, n_expert), block, lds, st, (const uint8_t *) W,             \
+                           rb, eb, M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off);                      \
+    } while (0)
     if (small) { if (f16) QMM_LAUNCH(64, true); else QMM_LAUNCH(64, false); }
     else       { if (f16) QMM_LAUNCH(128, true); else QMM_LAUNCH(128, false); }
 #undef QMM_LAUNCH
