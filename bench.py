@@ -34,23 +34,20 @@ def log(*a):
 
 
 def roofline_leg(hp, q, n_tokens, torch):
-    """per-launch HIP-event timing of one eager pass, with the GPU kept busy by a spin kernel while the host
-    enqueues (so the event pairs bracket back-to-back kernels, not host launch gaps)"""
+    """HIP-event timing of the pass's launches, bucketed by kernel.  The model's 32 layers give every launch shape 16-32
+    distinct weight sets, so each bucket is issued back to back on rotating weights (no Infinity-Cache reuse) inside ONE
+    event pair on the launch stream, behind a spin kernel that keeps the host ahead of the GPU.  Average launch duration
+    = bucket time / launches (it includes the kernel-to-kernel boundary, not a per-launch event cost)."""
     x, dst_local, _, ids = hp.prepare(n_tokens)
-    recs = []
-    torch.cuda.synchronize()
-    torch.cuda._sleep(int(2.0e8))
+    buckets = {}
     for grp in hp.wl.groups:
         m0 = grp.mats[0]
         if m0.n_expert:
             for m in grp.mats:
                 ne11 = m.n_used if m.name.endswith("down_exps") else 1
                 w, _ = hp.weights[m.name]
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                q.mul_mat_id(m.type, w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=dst_local[("id", m.M)])
-                e1.record()
-                recs.append((("id", m.type), m.algo_bytes(n_tokens), m.flops(n_tokens), e0, e1))
+                fn = (lambda m=m, w=w, ne11=ne11: q.mul_mat_id(m.type, w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=dst_local[("id", m.M)]))
+                buckets.setdefault(("id", m.type), []).append((fn, m.algo_bytes(n_tokens), m.flops(n_tokens)))
             continue
         # one launch per run of same-type weights inside the group (that is how qmm_mul_mat_group issues them)
         i = 0
@@ -60,29 +57,31 @@ def roofline_leg(hp, q, n_tokens, torch):
                 j += 1
             if n_tokens > 8:
                 j = i + 1
-            ws, outs, nbytes, fl = [], [], 0, 0
+            ws, outs, nbytes, fl = [], [], n_tokens * m0.K * 4, 0
             for m in grp.mats[i:j]:
                 w, _ = hp.weights[m.name]
                 ws.append((m.type, w))
                 outs.append(dst_local[(m.name.split(".")[-1], w.shape[0])])
-                rows = w.shape[0]
-                nbytes += w.numel() + n_tokens * rows * 4
-                fl += 2 * rows * m.K * n_tokens
-            nbytes += n_tokens * m0.K * 4
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            q.mul_mat_group(ws, m0.K, x[m0.K], outs)
-            e1.record()
-            recs.append((("mm", grp.mats[i].type), nbytes, fl, e0, e1))
+                nbytes += w.numel() + n_tokens * w.shape[0] * 4
+                fl += 2 * w.shape[0] * m.K * n_tokens
+            fn = (lambda ws=ws, outs=outs, K=m0.K: q.mul_mat_group(ws, K, x[K], outs))
+            buckets.setdefault(("mm", grp.mats[i].type), []).append((fn, nbytes, fl))
             i = j
     torch.cuda.synchronize()
+    torch.cuda._sleep(int(2.0e8))
+    evs = {}
+    for key, items in buckets.items():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for fn, _, _ in items:
+            fn()
+        e1.record()
+        evs[key] = (e0, e1)
+    torch.cuda.synchronize()
     agg = {}
-    for key, nb, fl, e0, e1 in recs:
-        a = agg.setdefault(key, [0, 0, 0.0, 0])
-        a[0] += nb
-        a[1] += fl
-        a[2] += e0.elapsed_time(e1) * 1e-3
-        a[3] += 1
+    for key, items in buckets.items():
+        e0, e1 = evs[key]
+        agg[key] = [sum(i[1] for i in items), sum(i[2] for i in items), e0.elapsed_time(e1) * 1e-3, len(items)]
     return agg
 
 

@@ -105,15 +105,41 @@ __device__ __forceinline__ void quantize_rows(const float * __restrict__ x, int6
     } else {
         const int lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = nthreads / WAVE;
         const int nb = K / 256;
-        for (int blk = wave; blk < rows * nb; blk += nwaves) {
-            const int r = blk / nb, b = blk % nb;
-            const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t) r * ldx + b * 256 + 4 * lane);
-            uint32_t p; float dd; int bs;
-            q8_K_block<BSG>(v, lane, p, dd, bs);
-            *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + act_pos<SWZ>(b * 256 + 4 * lane)) = p;
-            if (lane == 0) d[(int64_t) r * nb + b] = dd;
-            constexpr int LPG = BSG / 4;                         // lanes per bsum group
-            if (bsum && (lane & (LPG - 1)) == 0) bsum[(int64_t) r * (K / BSG) + b * (256 / BSG) + lane / LPG] = (int16_t) bs;
+        const int total = rows * nb;
+        constexpr int LPG = BSG / 4;                             // lanes per bsum group
+        // a wave's blocks are fetched four at a time (unconditional, clamped loads) so that a long row
+        // (K = 14336: 56 blocks over 16 waves) pays one L2/HBM round trip per four blocks, not per block
+        if (total <= nwaves) {                                   // at most one block per wave (K = 4096 at batch 1)
+            if (wave < total) {
+                const int r = wave / nb, b = wave % nb;
+                const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t) r * ldx + b * 256 + 4 * lane);
+                uint32_t p; float dd; int bs;
+                q8_K_block<BSG>(v, lane, p, dd, bs);
+                *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + act_pos<SWZ>(b * 256 + 4 * lane)) = p;
+                if (lane == 0) d[(int64_t) r * nb + b] = dd;
+                if (bsum && (lane & (LPG - 1)) == 0) bsum[(int64_t) r * (K / BSG) + b * (256 / BSG) + lane / LPG] = (int16_t) bs;
+            }
+            return;
+        }
+        for (int blk0 = wave; blk0 < total; blk0 += 4 * nwaves) {
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int blk = min(blk0 + j * nwaves, total - 1);
+                v[j] = *reinterpret_cast<const float4 *>(x + (int64_t) (blk / nb) * ldx + (blk % nb) * 256 + 4 * lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int blk = blk0 + j * nwaves;
+                if (blk < total) {                               // wave-uniform, no load inside
+                    const int r = blk / nb, b = blk % nb;
+                    uint32_t p; float dd; int bs;
+                    q8_K_block<BSG>(v[j], lane, p, dd, bs);
+                    *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + act_pos<SWZ>(b * 256 + 4 * lane)) = p;
+                    if (lane == 0) d[(int64_t) r * nb + b] = dd;
+                    if (bsum && (lane & (LPG - 1)) == 0) bsum[(int64_t) r * (K / BSG) + b * (256 / BSG) + lane / LPG] = (int16_t) bs;
+                }
+            }
         }
     }
 }

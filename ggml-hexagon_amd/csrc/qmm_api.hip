@@ -158,7 +158,7 @@ int qmm_device_info(const qmm_ctx * c, char * name, size_t name_len, size_t * me
 }
 
 int qmm_set_act_mode(qmm_ctx * c, int m) {
-    if (!c || ((m & 0xff) != QMM_ACT_REF && (m & 0xff) != QMM_ACT_X86)) return fail(QMM_EINVAL, "bad act mode");
+    if (!c || (m != QMM_ACT_REF && m != QMM_ACT_X86)) return fail(QMM_EINVAL, "bad act mode");
     c->act_mode = m;
     return QMM_OK;
 }

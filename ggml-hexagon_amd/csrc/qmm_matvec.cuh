@@ -71,10 +71,6 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
 
     const uint8_t * wrow; float * drow; int64_t ldd;
     locate(min(gw, total_rows - 1), wrow, drow, ldd);
-#ifdef QMM_MV_PREFETCH
-    MvUnit<T> first;
-    first.load(wrow, min(lane, units - 1));
-#endif
 
     quantize_rows<ACT, MvUnit<T>::BSG, T>(x, ldx, NTOK, K, act_mode, aq, ad, ACT == T_Q8_K ? ab : nullptr, tid, blockDim.x);
     __syncthreads();
@@ -83,15 +79,11 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
         float acc[NTOK];
 #pragma unroll
         for (int n = 0; n < NTOK; ++n) acc[n] = 0.0f;
-        for (int it = 0; it < iters; ++it) {
+        int it = 0;
+        for (; it < iters; ++it) {
             const int u = lane + WAVE * it, uc = min(u, units - 1);
             MvUnit<T> un;
-#ifdef QMM_MV_PREFETCH
-            if (it == 0 && row == gw) un = first;            // wave-uniform
-            else un.load(wrow, uc);
-#else
             un.load(wrow, uc);
-#endif
 #pragma unroll
             for (int n = 0; n < NTOK; ++n) {
                 const float p = un.dot(uc, aq + (size_t) n * K, ad + (size_t) n * (K / act_block<T>()), ab + (size_t) n * (K / MvUnit<T>::BSG));
