@@ -129,3 +129,73 @@ def test_rowsplit_concat_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# ---- the bench driver's multi-GPU path (HotPath + RowConcat) on CPU tensors, world_size 2, gloo, with the kernels replaced
+#      by the oracle (allowed here: tests may use the oracle as the checker/stand-in; the product path never does)
+
+class _OracleQmm:
+    """same method surface as capi.Qmm, computing with oracle/qmm_oracle.c on CPU tensors"""
+
+    def __init__(self):
+        from oracle.pyoracle import Oracle
+        self.o = Oracle()
+
+    def mul_mat_group(self, weights, k, x, outs):
+        import torch
+        for (t, w), out in zip(weights, outs):
+            out.copy_(torch.from_numpy(self.o.mul_mat(t, w.numpy(), k, x.numpy())))
+        return outs
+
+
+def _hotpath_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ggml_hexagon_amd import rowsplit, synth, workload
+        from ggml_hexagon_amd.hotpath import HotPath
+        # a 2-layer toy model with the real per-layer structure (grouped q/k/v with mixed types, gate/up, down, output)
+        wl = workload._llama("toy", 2, 256, 512, 4, 2, 1000, "q4_k_m")
+        orig = synth.synth_weights_torch
+        synth.synth_weights_torch = lambda t, rows, k, device, seed=0, sigma=0.02: torch.from_numpy(synth.synth_weights(t, rows, k, seed=seed, sigma=0.2))
+        try:
+            qm = _OracleQmm()
+            hp = HotPath(qm, wl, torch.device("cpu"), rank, world, rowsplit.RowConcat(), seed=5)
+            for n in (1, 3):
+                hp.run(n)
+                x, dst_local, dst_full, _ = hp.prepare(n)
+                # every full dst must equal the single-device product of the concatenated shards
+                for grp in wl.groups[-2:]:                       # last layer's ffn_down + the output projection (ragged split)
+                    for m in grp.mats:
+                        w_local, ranges = hp.weights[m.name]
+                        parts = [torch.zeros(0)] * world
+                        gathered = [None] * world
+                        dist.all_gather_object(gathered, w_local.numpy())
+                        w_full = np.concatenate([g for g in gathered if g.shape[0] > 0])
+                        want = qm.o.mul_mat(m.type, w_full, m.K, x[m.K].numpy())
+                        got = dst_full[(m.name.split(".")[-1], w_local.shape[0])].numpy()
+                        assert got.shape == want.shape and np.array_equal(got, want), m.name
+            q.put((rank, True))
+        finally:
+            synth.synth_weights_torch = orig
+    except Exception as e:
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()[-800:]}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hotpath_rowsplit_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hotpath_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)], res
