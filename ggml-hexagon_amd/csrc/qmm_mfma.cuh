@@ -61,7 +61,9 @@ template <bool F16> __device__ __forceinline__ uint32_t pack16(float a, float b)
 // stage 1: activation rows -> MFMA operand rows.  One workgroup per output row.
 //   src row r: x + gather(r)   (gather == nullptr: r*ldx; MoE: element offset of the pair's src1 row)
 //   out row r: xh + r*Kp   (16-bit), scale[r]
-template <int ACT, bool F16Q8>
+// PERM4: store every aligned group of four k as (0, 2, 1, 3) — the order in which the fast f16 weight unpack
+// (unpack_q4k_f16 below) produces its values; MFMA sums over k, so any order shared by both operands is fine.
+template <int ACT, bool F16Q8, bool PERM4>
 __global__ void __launch_bounds__(256)
 prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t * __restrict__ gather,
                 const int * __restrict__ n_rows_dev, const int n_rows, const int K, const int Kp, const int act_mode,
@@ -115,12 +117,50 @@ prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t *
                 v[i]     = (float) (int8_t) ((qq.x >> (8 * i)) & 0xff) * t;
                 v[4 + i] = (float) (int8_t) ((qq.y >> (8 * i)) & 0xff) * t;
             }
-            o = make_uint4(pack_f16(v[0], v[1]), pack_f16(v[2], v[3]), pack_f16(v[4], v[5]), pack_f16(v[6], v[7]));
+            o = PERM4 ? make_uint4(pack_f16(v[0], v[2]), pack_f16(v[1], v[3]), pack_f16(v[4], v[6]), pack_f16(v[5], v[7]))
+                      : make_uint4(pack_f16(v[0], v[1]), pack_f16(v[2], v[3]), pack_f16(v[4], v[5]), pack_f16(v[6], v[7]));
         }
         *reinterpret_cast<uint4 *>(out + k) = o;
     }
     if (tid == 0) scale[r] = mx;
 }
+
+// Q4_K -> f16 without leaving the packed domain: a nibble n OR-ed into 0x6400 is the f16 1024 + n; subtracting 1024
+// (exact) and one packed FMA with the f16-rounded sub-block scale and offset give w = ds*n - om.  Three roundings of
+// <= 2^-11 instead of one, ~2.5 VALU per weight instead of ~5.5.  Output dword pairs hold (k, k+2), (k+1, k+3): PERM4.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t h2_bits(f16x2 v) { return *reinterpret_cast<uint32_t *>(&v); }
+__device__ __forceinline__ f16x2 bits_h2(uint32_t u) { return *reinterpret_cast<f16x2 *>(&u); }
+
+__device__ __forceinline__ void unpack_q4k_f16(const Unit<T_Q4_K> & wu, int j, uint4 (&lo)[2], uint4 (&hi)[2]) {
+    int s0, m0, s1, m1;
+    k4_scale_min(wu.hdr, 2 * j, s0, m0);
+    k4_scale_min(wu.hdr, 2 * j + 1, s1, m1);
+    const float d = h2f(wu.hdr.x & 0xffff), dmin = h2f(wu.hdr.x >> 16);
+    const _Float16 ds0 = (_Float16) (d * (float) s0), ds1 = (_Float16) (d * (float) s1);
+    const _Float16 no0 = (_Float16) (-(dmin * (float) m0)), no1 = (_Float16) (-(dmin * (float) m1));
+    const f16x2 DS0 = { ds0, ds0 }, DS1 = { ds1, ds1 }, NO0 = { no0, no0 }, NO1 = { no1, no1 };
+    const f16x2 BIAS = { (_Float16) -1024.0f, (_Float16) -1024.0f };
+    const uint32_t w[4] = { wu.qs.x, wu.qs.y, wu.qs.z, wu.qs.w };
+    uint32_t ol[8], oh[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t M = 0x000f000fu, E = 0x64006400u;
+        const f16x2 a = bits_h2((w[i] & M) | E) + BIAS;               // bytes 0,2 low nibbles
+        const f16x2 b = bits_h2(((w[i] >> 8) & M) | E) + BIAS;        // bytes 1,3 low nibbles
+        const f16x2 c = bits_h2(((w[i] >> 4) & M) | E) + BIAS;        // bytes 0,2 high nibbles
+        const f16x2 e = bits_h2(((w[i] >> 12) & M) | E) + BIAS;       // bytes 1,3 high nibbles
+        ol[2 * i]     = h2_bits(__builtin_elementwise_fma(a, DS0, NO0));
+        ol[2 * i + 1] = h2_bits(__builtin_elementwise_fma(b, DS0, NO0));
+        oh[2 * i]     = h2_bits(__builtin_elementwise_fma(c, DS1, NO1));
+        oh[2 * i + 1] = h2_bits(__builtin_elementwise_fma(e, DS1, NO1));
+    }
+    lo[0] = make_uint4(ol[0], ol[1], ol[2], ol[3]); lo[1] = make_uint4(ol[4], ol[5], ol[6], ol[7]);
+    hi[0] = make_uint4(oh[0], oh[1], oh[2], oh[3]); hi[1] = make_uint4(oh[4], oh[5], oh[6], oh[7]);
+}
+
+template <int T, bool F16> struct MfmaPerm4 { static constexpr bool value = false; };
+template <> struct MfmaPerm4<T_Q4_K, true> { static constexpr bool value = true; };
 
 // ------------------------------------------------------------------------------------------------
 // stage 2.  Wave-specialized workgroup of 8 waves (512 threads) per BN x BM tile of dst:
@@ -188,7 +228,17 @@ mfma_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64
             uint8_t * Ws = stage;
             uint8_t * Xs = stage + BM * ROWB;
             const int u = min(ks * UPS + (tid & 1), units_per_row - 1);
-            if (has_w) {
+            if constexpr (MfmaPerm4<T, F16>::value) {
+                if (has_w) {
+                    uint4 lo[2], hi[2];
+                    unpack_q4k_f16(r.wu, (u & 7) >> 1, lo, hi);
+                    const int kk = Unit<T>::k_run(tid & 1, 0) & (BK - 1);         // low-nibble run; the high-nibble run is 32 further
+                    *reinterpret_cast<uint4 *>(Ws + tile_off<BK>(wr, (kk >> 3)))     = lo[0];
+                    *reinterpret_cast<uint4 *>(Ws + tile_off<BK>(wr, (kk >> 3) + 1)) = lo[1];
+                    *reinterpret_cast<uint4 *>(Ws + tile_off<BK>(wr, (kk >> 3) + 4)) = hi[0];
+                    *reinterpret_cast<uint4 *>(Ws + tile_off<BK>(wr, (kk >> 3) + 5)) = hi[1];
+                }
+            } else if (has_w) {
                 float v[Traits<T>::UNIT_W];
                 r.wu.to_f32(u, v);
 #pragma unroll
@@ -213,15 +263,18 @@ mfma_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64
         };
 
         // register ring: PF K-steps of loads in flight per thread (HBM/L2 latency under load is ~1 us, a K-step ~0.2 us)
-        constexpr int PF = 2;
+#ifndef QMM_MFMA_PF
+#define QMM_MFMA_PF 2
+#endif
+        constexpr int PF = QMM_MFMA_PF;
         Regs ring[PF];
 #pragma unroll
         for (int i = 0; i < PF; ++i) fetch(ring[i], i);
         stash(ring[0], 0, lds);
         fetch(ring[0], PF);
         __syncthreads();
-        for (int ks = 0; ks < nk; ks += PF) {                 // nk % PF == 0 is not required: indices are clamped, extra
-#pragma unroll                                                 // iterations past nk are skipped below
+        for (int ks = 0; ks < nk; ks += PF) {                 // indices are clamped; iterations past nk are skipped
+#pragma unroll
             for (int i = 1; i <= PF; ++i) {
                 if (ks + i - 1 < nk) {                        // uniform; matches the consumers' barrier count
                     const int slot = i % PF;
@@ -324,14 +377,17 @@ struct MfmaOperand {            // a prepared activation matrix in the workspace
 };
 
 template <int ACT>
-inline int launch_prep(qmm_ctx * c, hipStream_t st, const float * x, int64_t ldx, const int64_t * gather, const int * n_dev,
+inline int launch_prep(qmm_ctx * c, hipStream_t st, int type, const float * x, int64_t ldx, const int64_t * gather, const int * n_dev,
                        int n_rows, int n_pad, int K, int Kp, uint16_t * xh, float * scale) {
     const size_t lds = (size_t) K + (size_t) (K / 32) * 4 + 64;
-    if (c->prec == QMM_PREC_F16_Q8)
-        hipLaunchKernelGGL((prep_act_kernel<ACT, true>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
+    if (c->prec == QMM_PREC_F16_Q8 && type == T_Q4_K)          // operand k-order of the fast Q4_K unpack (MfmaPerm4)
+        hipLaunchKernelGGL((prep_act_kernel<ACT, true, true>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
+                           c->act_mode, xh, scale);
+    else if (c->prec == QMM_PREC_F16_Q8)
+        hipLaunchKernelGGL((prep_act_kernel<ACT, true, false>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
                            c->act_mode, xh, scale);
     else
-        hipLaunchKernelGGL((prep_act_kernel<ACT, false>), dim3(n_pad), dim3(256), 0, st, x, ldx, gather, n_dev, n_rows, K, Kp,
+        hipLaunchKernelGGL((prep_act_kernel<ACT, false, false>), dim3(n_pad), dim3(256), 0, st, x, ldx, gather, n_dev, n_rows, K, Kp,
                            c->act_mode, xh, scale);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
@@ -386,8 +442,8 @@ inline int mfma_mul_mat(qmm_ctx * c, hipStream_t st, int type, const void * W, i
     if (!reuse_prep || c->prec == QMM_PREC_F16_Q8) {
         // (with Q8 emulation the operand depends on the weight type's activation format, so only same-format
         //  neighbours could share it; keep it simple and prepare per call)
-        rc = q8_0 ? launch_prep<T_Q8_0>(c, st, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, xh, scale)
-                  : launch_prep<T_Q8_K>(c, st, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, xh, scale);
+        rc = q8_0 ? launch_prep<T_Q8_0>(c, st, type, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, xh, scale)
+                  : launch_prep<T_Q8_K>(c, st, type, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, xh, scale);
         if (rc) return rc;
     }
     MfmaOperand op = { xh, scale, Kp };

@@ -164,8 +164,8 @@ inline int moe_mul_mat_id(qmm_ctx * c, hipStream_t st, int type, const void * as
                        (int) n_expert, (int) ne11, b_s1, b_s2, d_s1, d_s2, seg_start, seg_count, n_live, gather, dst_off, c->flag);
     HIP_TRY(hipGetLastError());
     const bool q8_0 = (type == T_Q4_0 || type == T_Q8_0);
-    rc = q8_0 ? launch_prep<T_Q8_0>(c, st, b, 0, gather, n_live, (int) P, (int) P, (int) K, Kp, xh, scale)
-              : launch_prep<T_Q8_K>(c, st, b, 0, gather, n_live, (int) P, (int) P, (int) K, Kp, xh, scale);
+    rc = q8_0 ? launch_prep<T_Q8_0>(c, st, type, b, 0, gather, n_live, (int) P, (int) P, (int) K, Kp, xh, scale)
+              : launch_prep<T_Q8_K>(c, st, type, b, 0, gather, n_live, (int) P, (int) P, (int) K, Kp, xh, scale);
     if (rc) return rc;
     MfmaOperand op = { xh, scale, Kp };
     return launch_mfma_any(c, st, type, as, rb, eb, (int) n_expert, (int) M, (int) K, op, seg_start, seg_count, (int) P,
