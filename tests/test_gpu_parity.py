@@ -303,3 +303,26 @@ def test_full_size_properties(qmm, oracle, t):
         ys = torch.cat([qmm.mul_mat(t, wd, k, xb[i:i + 8].contiguous()) for i in range(0, 64, 8)])
         err = torch.linalg.norm(yb - ys) / torch.linalg.norm(ys)
         assert float(err) < 1e-3
+
+
+# ----------------------------------------------------------------------------- strides (views, as ggml hands them over)
+
+@pytest.mark.parametrize("n", [3, 40])
+def test_strided_operands(qmm, oracle, n):
+    """src1 rows ldx > K apart, weight rows nb01 > row size apart, dst rows ldd > M apart — both kernels"""
+    import ggml_hexagon_amd.synth as synth
+    for t, k in ((Q4_K, 512), (Q6_K, 256), (Q4_0, 160), (Q8_0, 96)):
+        m = 70
+        w = synth.synth_weights(t, m, k, seed=k, sigma=0.2)
+        rb = w.shape[1]
+        wbig = torch.zeros((m, rb + 32), dtype=torch.uint8, device="cuda")
+        wbig[:, :rb] = dev(w)
+        x = np.random.default_rng(k + n).uniform(-1, 1, (n, k)).astype(np.float32)
+        xbig = torch.full((n, k + 64), 9.0, device="cuda")
+        xbig[:, :k] = dev(x)
+        out = torch.full((n, m + 10), 5.0, device="cuda")
+        qmm.mul_mat(t, wbig[:, :rb], k, xbig[:, :k], out=out[:, :m])
+        o = out.cpu().numpy()
+        assert (o[:, m:] == 5.0).all()
+        want = oracle.mul_mat(t, w, k, x, ACT_REF)
+        assert (rel_rms(o[:, :m], want) < 2e-5) if n <= 8 else (rel_l2(o[:, :m], want) < 1e-3)
