@@ -53,16 +53,20 @@ __device__ __forceinline__ int magic_round(float prod) {
 template <int BSG>
 __device__ __forceinline__ void q8_K_block(const float4 v, int lane, uint32_t & packed, float & d_out, int & bsum) {
 #pragma clang fp contract(off)      // the product must round to f32 BEFORE the magic add (hipcc contracts __fmul_rn/__fadd_rn too)
-    // first element with the largest |x| decides the sign of the scale (strict '>' scan in the reference):
-    // wave max of |x| on DPP, then the lowest lane that holds it supplies its own first maximum
-    float best = fabsf(v.x), bval = v.x;
-    if (fabsf(v.y) > best) { best = fabsf(v.y); bval = v.y; }
-    if (fabsf(v.z) > best) { best = fabsf(v.z); bval = v.z; }
-    if (fabsf(v.w) > best) { best = fabsf(v.w); bval = v.w; }
-    const float gmax = wave_max(best);
-    const unsigned long long holders = __ballot(best == gmax);
+    // first element with the largest |x| decides the sign of the scale (strict '>' scan in the reference): the wave max
+    // of |x| is taken on the bit patterns (no float-max canonicalisation), then the lowest lane that holds it supplies
+    // its own first maximum
+    const uint32_t ax = __float_as_uint(v.x) & 0x7fffffffu, ay = __float_as_uint(v.y) & 0x7fffffffu;
+    const uint32_t az = __float_as_uint(v.z) & 0x7fffffffu, aw = __float_as_uint(v.w) & 0x7fffffffu;
+    uint32_t bbits = ax;
+    float bval = v.x;
+    if (ay > bbits) { bbits = ay; bval = v.y; }
+    if (az > bbits) { bbits = az; bval = v.z; }
+    if (aw > bbits) { bbits = aw; bval = v.w; }
+    const uint32_t gbits = wave_max_u32(bbits);
+    const unsigned long long holders = __ballot(bbits == gbits);
     bval = readlane_f(bval, __builtin_amdgcn_readfirstlane((int) __ffsll((long long) holders) - 1));
-    best = gmax;
+    const float best = __uint_as_float(gbits);
     if (best == 0.0f) {            // reference: d = 0, qs = 0 (bsums left as they were; we define 0)
         packed = 0; d_out = 0.0f; bsum = 0;
         return;
@@ -105,40 +109,31 @@ __device__ __forceinline__ void quantize_rows(const float * __restrict__ x, int6
     } else {
         const int lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = nthreads / WAVE;
         const int nb = K / 256;
-        const int total = rows * nb;
         constexpr int LPG = BSG / 4;                             // lanes per bsum group
-        // a wave's blocks are fetched four at a time (unconditional, clamped loads) so that a long row
-        // (K = 14336: 56 blocks over 16 waves) pays one L2/HBM round trip per four blocks, not per block
-        if (total <= nwaves) {                                   // at most one block per wave (K = 4096 at batch 1)
-            if (wave < total) {
-                const int r = wave / nb, b = wave % nb;
-                const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t) r * ldx + b * 256 + 4 * lane);
-                uint32_t p; float dd; int bs;
-                q8_K_block<BSG>(v, lane, p, dd, bs);
-                *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + act_pos<SWZ>(b * 256 + 4 * lane)) = p;
-                if (lane == 0) d[(int64_t) r * nb + b] = dd;
-                if (bsum && (lane & (LPG - 1)) == 0) bsum[(int64_t) r * (K / BSG) + b * (256 / BSG) + lane / LPG] = (int16_t) bs;
+        auto emit = [&](const float4 v, int8_t * qr, float * dr, int16_t * br, int b) {
+            uint32_t p; float dd; int bs;
+            q8_K_block<BSG>(v, lane, p, dd, bs);
+            *reinterpret_cast<uint32_t *>(qr + act_pos<SWZ>(b * 256 + 4 * lane)) = p;
+            if (lane == 0) dr[b] = dd;
+            if (br && (lane & (LPG - 1)) == 0) br[b * (256 / BSG) + lane / LPG] = (int16_t) bs;
+        };
+        for (int r = 0; r < rows; ++r) {                         // rows is a small compile-time constant at the hot call sites
+            const float * xr = x + (int64_t) r * ldx + 4 * lane;
+            int8_t *  qr = q + (size_t) r * K;
+            float *   dr = d + (size_t) r * nb;
+            int16_t * br = bsum ? bsum + (size_t) r * (K / BSG) : nullptr;
+            if (nb <= nwaves) {                                  // at most one block per wave (K = 4096 with 16 waves)
+                if (wave < nb) emit(*reinterpret_cast<const float4 *>(xr + wave * 256), qr, dr, br, wave);
+                continue;
             }
-            return;
-        }
-        for (int blk0 = wave; blk0 < total; blk0 += 4 * nwaves) {
-            float4 v[4];
+            // long rows (K = 14336: 56 blocks over 16 waves): four blocks' loads in flight per wave, unconditional + clamped
+            for (int b0 = wave; b0 < nb; b0 += 4 * nwaves) {
+                float4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int blk = min(blk0 + j * nwaves, total - 1);
-                v[j] = *reinterpret_cast<const float4 *>(x + (int64_t) (blk / nb) * ldx + (blk % nb) * 256 + 4 * lane);
-            }
+                for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4 *>(xr + min(b0 + j * nwaves, nb - 1) * 256);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int blk = blk0 + j * nwaves;
-                if (blk < total) {                               // wave-uniform, no load inside
-                    const int r = blk / nb, b = blk % nb;
-                    uint32_t p; float dd; int bs;
-                    q8_K_block<BSG>(v[j], lane, p, dd, bs);
-                    *reinterpret_cast<uint32_t *>(q + (int64_t) r * K + act_pos<SWZ>(b * 256 + 4 * lane)) = p;
-                    if (lane == 0) d[(int64_t) r * nb + b] = dd;
-                    if (bsum && (lane & (LPG - 1)) == 0) bsum[(int64_t) r * (K / BSG) + b * (256 / BSG) + lane / LPG] = (int16_t) bs;
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (b0 + j * nwaves < nb) emit(v[j], qr, dr, br, b0 + j * nwaves);     // wave-uniform, no load inside
             }
         }
     }

@@ -382,6 +382,16 @@ __device__ __forceinline__ float wave_sum(float v) {          // result in every
     v += dpp_mov<DPP_ROW_MIRROR>(v);
     return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
+// max of non-negative floats through their bit patterns (monotonic as unsigned ints): no NaN canonicalisation ops
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, (uint32_t) dpp_mov_i<DPP_QUAD_X1>((int) v));
+    v = max(v, (uint32_t) dpp_mov_i<DPP_QUAD_X2>((int) v));
+    v = max(v, (uint32_t) dpp_mov_i<DPP_ROW_HALF_MIRROR>((int) v));
+    v = max(v, (uint32_t) dpp_mov_i<DPP_ROW_MIRROR>((int) v));
+    const uint32_t a = (uint32_t) __builtin_amdgcn_readlane((int) v, 0), b = (uint32_t) __builtin_amdgcn_readlane((int) v, 16);
+    const uint32_t c = (uint32_t) __builtin_amdgcn_readlane((int) v, 32), d = (uint32_t) __builtin_amdgcn_readlane((int) v, 48);
+    return max(max(a, b), max(c, d));
+}
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_mov<DPP_QUAD_X1>(v));
     v = fmaxf(v, dpp_mov<DPP_QUAD_X2>(v));

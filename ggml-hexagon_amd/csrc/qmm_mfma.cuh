@@ -159,8 +159,40 @@ __device__ __forceinline__ void unpack_q4k_f16(const Unit<T_Q4_K> & wu, int j, u
     hi[0] = make_uint4(oh[0], oh[1], oh[2], oh[3]); hi[1] = make_uint4(oh[4], oh[5], oh[6], oh[7]);
 }
 
+// Q6_K the same way: the four 6-bit values of a byte column are assembled packed (ql nibble | qh pair << 4), OR-ed into
+// 0x6400 as byte pairs (0,2) / (1,3), rebased by -(1024 + 32) (exact) and multiplied by the f16-rounded d * sc.
+__device__ __forceinline__ void unpack_q6k_f16(const Unit<T_Q6_K> & wu, int g, uint4 (&out)[4][2]) {
+    const float d = h2f(wu.d);
+    f16x2 DS[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const _Float16 t = (_Float16) (d * (float) wu.scale(g, r)); DS[r] = f16x2{ t, t }; }
+    const f16x2 BIAS = { (_Float16) -1056.0f, (_Float16) -1056.0f };
+    const uint32_t A[4] = { wu.qa.x, wu.qa.y, wu.qa.z, wu.qa.w }, B[4] = { wu.qb.x, wu.qb.y, wu.qb.z, wu.qb.w },
+                   H[4] = { wu.qh.x, wu.qh.y, wu.qh.z, wu.qh.w };
+    uint32_t o[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t m4 = 0x0f0f0f0fu, m2 = 0x30303030u, P = 0x00ff00ffu, E = 0x64006400u;
+        const uint32_t v[4] = { (A[i] & m4) | ((H[i] << 4) & m2), (B[i] & m4) | ((H[i] << 2) & m2),
+                                ((A[i] >> 4) & m4) | (H[i] & m2), ((B[i] >> 4) & m4) | ((H[i] >> 2) & m2) };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f16x2 a = (bits_h2((v[r] & P) | E) + BIAS) * DS[r];            // l = 4i, 4i+2
+            const f16x2 b = (bits_h2(((v[r] >> 8) & P) | E) + BIAS) * DS[r];     // l = 4i+1, 4i+3
+            o[r][2 * i] = h2_bits(a);
+            o[r][2 * i + 1] = h2_bits(b);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        out[r][0] = make_uint4(o[r][0], o[r][1], o[r][2], o[r][3]);
+        out[r][1] = make_uint4(o[r][4], o[r][5], o[r][6], o[r][7]);
+    }
+}
+
 template <int T, bool F16> struct MfmaPerm4 { static constexpr bool value = false; };
 template <> struct MfmaPerm4<T_Q4_K, true> { static constexpr bool value = true; };
+template <> struct MfmaPerm4<T_Q6_K, true> { static constexpr bool value = true; };
 
 // ------------------------------------------------------------------------------------------------
 // stage 2.  Wave-specialized workgroup of 8 waves (512 threads) per BN x BM tile of dst:
@@ -228,7 +260,18 @@ mfma_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64
             uint8_t * Ws = stage;
             uint8_t * Xs = stage + BM * ROWB;
             const int u = min(ks * UPS + (tid & 1), units_per_row - 1);
-            if constexpr (MfmaPerm4<T, F16>::value) {
+            if constexpr (MfmaPerm4<T, F16>::value && T == T_Q6_K) {
+                if (has_w) {
+                    uint4 o[4][2];
+                    unpack_q6k_f16(r.wu, u & 1, o);
+                    const int s0 = (Unit<T>::k_run(tid & 1, 0) & (BK - 1)) >> 3;  // run r sits 32 k = 4 slots further each
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        *reinterpret_cast<uint4 *>(Ws + tile_off<BK>(wr, s0 + 4 * rr))     = o[rr][0];
+                        *reinterpret_cast<uint4 *>(Ws + tile_off<BK>(wr, s0 + 4 * rr + 1)) = o[rr][1];
+                    }
+                }
+            } else if constexpr (MfmaPerm4<T, F16>::value) {
                 if (has_w) {
                     uint4 lo[2], hi[2];
                     unpack_q4k_f16(r.wu, (u & 7) >> 1, lo, hi);
@@ -380,7 +423,7 @@ template <int ACT>
 inline int launch_prep(qmm_ctx * c, hipStream_t st, int type, const float * x, int64_t ldx, const int64_t * gather, const int * n_dev,
                        int n_rows, int n_pad, int K, int Kp, uint16_t * xh, float * scale) {
     const size_t lds = (size_t) K + (size_t) (K / 32) * 4 + 64;
-    if (c->prec == QMM_PREC_F16_Q8 && type == T_Q4_K)          // operand k-order of the fast Q4_K unpack (MfmaPerm4)
+    if (c->prec == QMM_PREC_F16_Q8 && (type == T_Q4_K || type == T_Q6_K))   // operand k-order of the packed-f16 unpacks (MfmaPerm4)
         hipLaunchKernelGGL((prep_act_kernel<ACT, true, true>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
                            c->act_mode, xh, scale);
     else if (c->prec == QMM_PREC_F16_Q8)
