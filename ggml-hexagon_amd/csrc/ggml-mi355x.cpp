@@ -185,8 +185,9 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, const ggml_tensor * c
     *consumed = 1;
     const int64_t K = a->ne[0], N = b->ne[1];
     const bool flat = a->ne[2] == 1 && a->ne[3] == 1 && b->ne[2] == 1 && b->ne[3] == 1;
-    if (flat && N <= QMM_MATVEC_MAX_N) {
-        // group the following MUL_MAT nodes that read the same src1 (wq/wk/wv, ffn gate/up): one launch per weight type
+    if (flat) {
+        // group the following MUL_MAT nodes that read the same src1 (wq/wk/wv, ffn gate/up): batch <= 8: one launch per
+        // weight type; larger batches: the 16-bit activation operand is prepared once per group
         qmm_weight ws[4];
         int n = 0;
         for (int i = 0; i < n_nodes && n < 4; ++i) {

@@ -305,10 +305,13 @@ int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, con
         }
         return QMM_OK;
     }
+    int last_key = -1;                   // the group shares src1: its 16-bit operand is prepared once per activation format
     for (int i = 0; i < nw; ++i) {
         if (ws[i].M == 0) continue;
-        int rc = mfma_mul_mat(c, st, ws[i].type, ws[i].w, ws[i].w_row_bytes, K, ws[i].M, x, N, ldx, ws[i].dst, ws[i].ldd, i > 0);
+        const int key = mfma_prep_key(c, ws[i].type);
+        int rc = mfma_mul_mat(c, st, ws[i].type, ws[i].w, ws[i].w_row_bytes, K, ws[i].M, x, N, ldx, ws[i].dst, ws[i].ldd, key == last_key);
         if (rc) return rc;
+        last_key = key;
     }
     return QMM_OK;
 }

@@ -471,7 +471,13 @@ inline int launch_mfma_any(qmm_ctx * c, hipStream_t st, int type, const void * W
     }
 }
 
-// plain MUL_MAT, N > 8.  `reuse_prep`: the previous call of a group already prepared the same src1.
+// what the prepared operand depends on besides src1 itself: Q8_0 vs Q8_K emulation and the k-order of the unpack
+inline int mfma_prep_key(const qmm_ctx * c, int type) {
+    if (c->prec != QMM_PREC_F16_Q8) return 0;
+    return 1 + ((type == T_Q4_0 || type == T_Q8_0) ? 1 : 0) + ((type == T_Q4_K || type == T_Q6_K) ? 2 : 0);
+}
+
+// plain MUL_MAT, N > 8.  `reuse_prep`: the previous call of a group already prepared the same src1 with the same key.
 inline int mfma_mul_mat(qmm_ctx * c, hipStream_t st, int type, const void * W, int64_t rb, int64_t K, int64_t M,
                         const float * x, int64_t N, int64_t ldx, float * dst, int64_t ldd, bool reuse_prep) {
     const int Kp = mfma_kpad(K), Np = mfma_npad(N);
@@ -482,9 +488,7 @@ inline int mfma_mul_mat(qmm_ctx * c, hipStream_t st, int type, const void * W, i
     uint16_t * xh = (uint16_t *) c->ws;
     float * scale = (float *) ((uint8_t *) c->ws + xh_bytes);
     const bool q8_0 = (type == T_Q4_0 || type == T_Q8_0);
-    if (!reuse_prep || c->prec == QMM_PREC_F16_Q8) {
-        // (with Q8 emulation the operand depends on the weight type's activation format, so only same-format
-        //  neighbours could share it; keep it simple and prepare per call)
+    if (!reuse_prep) {           // the caller guarantees: same src1, same activation format and k-order as the previous call
         rc = q8_0 ? launch_prep<T_Q8_0>(c, st, type, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, xh, scale)
                   : launch_prep<T_Q8_K>(c, st, type, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, xh, scale);
         if (rc) return rc;
