@@ -5,6 +5,7 @@
 
 #include "qmm_matvec.cuh"
 #include "qmm_mfma.cuh"
+#include "qmm_mfma_regb.cuh"
 #include "qmm_moe.cuh"
 
 using namespace qmm;

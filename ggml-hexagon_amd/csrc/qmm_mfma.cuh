@@ -61,9 +61,12 @@ template <bool F16> __device__ __forceinline__ uint32_t pack16(float a, float b)
 // stage 1: activation rows -> MFMA operand rows.  One workgroup per output row.
 //   src row r: x + gather(r)   (gather == nullptr: r*ldx; MoE: element offset of the pair's src1 row)
 //   out row r: xh + r*Kp   (16-bit), scale[r]
-// PERM4: store every aligned group of four k as (0, 2, 1, 3) — the order in which the fast f16 weight unpack
-// (unpack_q4k_f16 below) produces its values; MFMA sums over k, so any order shared by both operands is fine.
-template <int ACT, bool F16Q8, bool PERM4>
+// PERM: the k-order in which the operand row is stored; MFMA sums over k, so any order shared by both operands is fine.
+//   0  natural
+//   1  every aligned group of four k as (0, 2, 1, 3): the order the packed-f16 unpacks (unpack_q6k_f16) produce
+//   2  per 64-block, position p = kk*16 + h*8 + e holds k = (kk&1)*8 + 16h + 32*(kk>>1) + (0,2,1,3,4,6,5,7)[e]: the order in
+//      which a lane of qmm_mfma_regb.cuh owns its 16 bytes of a Q4_K sub-block pair (h = lane half, kk = MFMA k-step)
+template <int ACT, bool F16Q8, int PERM>
 __global__ void __launch_bounds__(256)
 prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t * __restrict__ gather,
                 const int * __restrict__ n_rows_dev, const int n_rows, const int K, const int Kp, const int act_mode,
@@ -109,15 +112,20 @@ prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t *
     for (int k = tid * 8; k < Kp; k += 256 * 8) {
         uint4 o = make_uint4(0, 0, 0, 0);
         if (k < K) {
-            const float t = ad[k / QB] * inv;                // |t| <= 1
-            const int2 qq = *reinterpret_cast<const int2 *>(aq + k);
+            int ksrc = k;
+            if (PERM == 2) {
+                const int p = k & 63, kk = p >> 4, h = (p >> 3) & 1;
+                ksrc = (k & ~63) + (kk & 1) * 8 + 16 * h + 32 * (kk >> 1);
+            }
+            const float t = ad[ksrc / QB] * inv;             // |t| <= 1
+            const int2 qq = *reinterpret_cast<const int2 *>(aq + ksrc);
             float v[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v[i]     = (float) (int8_t) ((qq.x >> (8 * i)) & 0xff) * t;
                 v[4 + i] = (float) (int8_t) ((qq.y >> (8 * i)) & 0xff) * t;
             }
-            o = PERM4 ? make_uint4(pack_f16(v[0], v[2]), pack_f16(v[1], v[3]), pack_f16(v[4], v[6]), pack_f16(v[5], v[7]))
+            o = PERM ? make_uint4(pack_f16(v[0], v[2]), pack_f16(v[1], v[3]), pack_f16(v[4], v[6]), pack_f16(v[5], v[7]))
                       : make_uint4(pack_f16(v[0], v[1]), pack_f16(v[2], v[3]), pack_f16(v[4], v[5]), pack_f16(v[6], v[7]));
         }
         *reinterpret_cast<uint4 *>(out + k) = o;
@@ -423,14 +431,17 @@ template <int ACT>
 inline int launch_prep(qmm_ctx * c, hipStream_t st, int type, const float * x, int64_t ldx, const int64_t * gather, const int * n_dev,
                        int n_rows, int n_pad, int K, int Kp, uint16_t * xh, float * scale) {
     const size_t lds = (size_t) K + (size_t) (K / 32) * 4 + 64;
-    if (c->prec == QMM_PREC_F16_Q8 && (type == T_Q4_K || type == T_Q6_K))   // operand k-order of the packed-f16 unpacks (MfmaPerm4)
-        hipLaunchKernelGGL((prep_act_kernel<ACT, true, true>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
+    if (c->prec == QMM_PREC_F16_Q8 && type == T_Q4_K)          // register-B kernel's lane order (qmm_mfma_regb.cuh)
+        hipLaunchKernelGGL((prep_act_kernel<ACT, true, 2>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
+                           c->act_mode, xh, scale);
+    else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q6_K)     // packed-f16 unpack order
+        hipLaunchKernelGGL((prep_act_kernel<ACT, true, 1>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
                            c->act_mode, xh, scale);
     else if (c->prec == QMM_PREC_F16_Q8)
-        hipLaunchKernelGGL((prep_act_kernel<ACT, true, false>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
+        hipLaunchKernelGGL((prep_act_kernel<ACT, true, 0>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
                            c->act_mode, xh, scale);
     else
-        hipLaunchKernelGGL((prep_act_kernel<ACT, false, false>), dim3(n_pad), dim3(256), 0, st, x, ldx, gather, n_dev, n_rows, K, Kp,
+        hipLaunchKernelGGL((prep_act_kernel<ACT, false, 0>), dim3(n_pad), dim3(256), 0, st, x, ldx, gather, n_dev, n_rows, K, Kp,
                            c->act_mode, xh, scale);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
@@ -459,9 +470,15 @@ inline int launch_mfma(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, 
     return QMM_OK;
 }
 
+int launch_mfma_regb_q4k(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
+                         const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
+                         float * dst, int64_t ldd, const int64_t * dst_off);
+
 inline int launch_mfma_any(qmm_ctx * c, hipStream_t st, int type, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
                            const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
                            float * dst, int64_t ldd, const int64_t * dst_off) {
+    if (type == T_Q4_K && c->prec == QMM_PREC_F16_Q8)
+        return launch_mfma_regb_q4k(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
     switch (type) {
         case T_Q4_0: return launch_mfma<T_Q4_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
         case T_Q8_0: return launch_mfma<T_Q8_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
@@ -474,7 +491,7 @@ inline int launch_mfma_any(qmm_ctx * c, hipStream_t st, int type, const void * W
 // what the prepared operand depends on besides src1 itself: Q8_0 vs Q8_K emulation and the k-order of the unpack
 inline int mfma_prep_key(const qmm_ctx * c, int type) {
     if (c->prec != QMM_PREC_F16_Q8) return 0;
-    return 1 + ((type == T_Q4_0 || type == T_Q8_0) ? 1 : 0) + ((type == T_Q4_K || type == T_Q6_K) ? 2 : 0);
+    return 1 + ((type == T_Q4_0 || type == T_Q8_0) ? 1 : 0) + (type == T_Q4_K ? 2 : 0) + (type == T_Q6_K ? 4 : 0);
 }
 
 // plain MUL_MAT, N > 8.  `reuse_prep`: the previous call of a group already prepared the same src1 with the same key.

@@ -1,0 +1,198 @@
+// qmm_mfma_regb.cuh — prefill kernel, "register-B" form (Q4_K, QMM_PREC_F16_Q8).
+//
+// Every wave owns 32 weight rows and ALL of the tile's 128 tokens.  A lane (row r = lane & 31, half h = lane >> 5) owns
+// 16 of the 32 qs bytes of its row's current sub-block pair: it loads them straight from HBM (one 16-byte load per
+// K-step), unpacks them in the packed-f16 domain (0x6400 | nibble, -1024, one packed FMA with the f16-rounded sub-scale
+// and offset) and the results ARE the MFMA B fragments of the four 16-deep MFMA k-steps of the K-step:
+//     kk = 0: low nibbles of bytes 0..7      kk = 1: low nibbles of bytes 8..15
+//     kk = 2: high nibbles of bytes 0..7     kk = 3: high nibbles of bytes 8..15
+// No LDS round trip, no cross-lane movement, no producer/consumer split for the weights.  Only the activation tile
+// (128 tokens x 64 k, f16, shared by the workgroup's waves) goes through LDS, double-buffered, already stored by
+// prep_act_kernel<.., 2> in the k-order this ownership implies.  One barrier per K-step; with 8 waves per workgroup
+// (256 rows) two waves share a SIMD and one wave's unpack VALU overlaps the other's MFMAs.
+//   D[token][row] += A[token][k] * B[k][row]:  A = activations (4 fragments per kk from LDS), B = this lane's registers.
+#pragma once
+
+#include "qmm_mfma.cuh"
+
+namespace qmm {
+
+// the lane's 16 bytes -> four B fragments (8 f16 each).  Element order inside a fragment: bytes (0,2,1,3,4,6,5,7).
+struct RegbFrag { uint4 f0, f1, f2, f3; };
+
+__device__ __forceinline__ RegbFrag regb_unpack_q4k(const uint4 qs, const uint4 hdr, int j) {
+    int s0, m0, s1, m1;
+    k4_scale_min(hdr, 2 * j, s0, m0);
+    k4_scale_min(hdr, 2 * j + 1, s1, m1);
+    const float d = h2f(hdr.x & 0xffff), dmin = h2f(hdr.x >> 16);
+    const _Float16 ds0 = (_Float16) (d * (float) s0), ds1 = (_Float16) (d * (float) s1);
+    const _Float16 no0 = (_Float16) (-(dmin * (float) m0)), no1 = (_Float16) (-(dmin * (float) m1));
+    const f16x2 DS0 = { ds0, ds0 }, DS1 = { ds1, ds1 }, NO0 = { no0, no0 }, NO1 = { no1, no1 };
+    const f16x2 BIAS = { (_Float16) -1024.0f, (_Float16) -1024.0f };
+    const uint32_t w[4] = { qs.x, qs.y, qs.z, qs.w };
+    uint32_t lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t M = 0x000f000fu, E = 0x64006400u;
+        lo[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2((w[i] & M) | E) + BIAS, DS0, NO0));           // bytes 4i, 4i+2
+        lo[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((w[i] >> 8) & M) | E) + BIAS, DS0, NO0));    // bytes 4i+1, 4i+3
+        hi[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2(((w[i] >> 4) & M) | E) + BIAS, DS1, NO1));
+        hi[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((w[i] >> 12) & M) | E) + BIAS, DS1, NO1));
+    }
+    RegbFrag fr;
+    fr.f0 = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    fr.f1 = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+    fr.f2 = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    fr.f3 = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+    return fr;
+}
+
+template <int NW>       // waves per workgroup: tile = 32*NW weight rows x 128 tokens
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
+mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64_t expert_bytes, const int M, const int K,
+                     const uint16_t * __restrict__ Xh, const int Kp, const float * __restrict__ scale,
+                     const int * __restrict__ seg_start, const int * __restrict__ seg_count, const int N,
+                     float * __restrict__ dst, const int64_t ldd, const int64_t * __restrict__ dst_off) {
+    constexpr int BN = 128, BK = 64, ROWB = BK * 2, SLOTS = 8;
+    constexpr int NT = NW * 64;
+    constexpr int X_CHUNKS = BN * SLOTS / NT;                 // 16-byte chunks of the activation tile per thread per K-step
+    constexpr int STAGE = BN * ROWB;                          // 16 KB
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seg0 = seg_start ? seg_start[blockIdx.z] : 0;
+    const int segn = seg_count ? seg_count[blockIdx.z] : N;
+    const int tok0 = blockIdx.y * BN;
+    if (tok0 >= segn) return;
+    const int row0 = blockIdx.x * (32 * NW) + wave * 32;
+    const int r = lane & 31, h = lane >> 5;
+    const uint8_t * wrow = W + (int64_t) blockIdx.z * expert_bytes + (int64_t) min(row0 + r, M - 1) * row_bytes;
+    const int nk = Kp / BK;                                   // K % 256 == 0 for Q4_K: nk is a multiple of 4
+    const int nblk = K / 256;
+
+    const uint8_t * xthr = reinterpret_cast<const uint8_t *>(Xh + (int64_t) (seg0 + tok0) * Kp) +
+                           (size_t) (tid / SLOTS) * Kp * 2 + (tid % SLOTS) * 16;
+    const int xrow_step = (NT / SLOTS) * Kp * 2;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+
+    // loads are unconditional; indices are clamped at the end of K (re-reads valid bytes, results unused)
+    auto load_qs  = [&](int ks) { const int k2 = min(ks, nk - 1); return ldg<uint4>(wrow + (size_t) (k2 >> 2) * 144 + 16 + 32 * (k2 & 3) + 16 * h); };
+    auto load_hdr = [&](int b)  { return ldg<uint4>(wrow + (size_t) min(b, nblk - 1) * 144); };
+    struct XRegs { uint4 c[X_CHUNKS]; };
+    auto load_x = [&](int ks) {
+        XRegs x;
+        const uint8_t * xp = xthr + min(ks, nk - 1) * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < X_CHUNKS; ++i) x.c[i] = *reinterpret_cast<const uint4 *>(xp + i * xrow_step);
+        return x;
+    };
+    auto store_x = [&](const XRegs x, uint8_t * stage) {
+#pragma unroll
+        for (int i = 0; i < X_CHUNKS; ++i) {
+            const int c = tid + NT * i;
+            *reinterpret_cast<uint4 *>(stage + tile_off<BK>(c / SLOTS, c % SLOTS)) = x.c[i];
+        }
+    };
+    // 4 fragment reads + 4 MFMAs per 16-deep k-step, on this lane's B fragment.  (Measured alternatives that did NOT help:
+    // pinning 8 reads ahead of the MFMAs with sched_group_barrier; interleaving the next K-step's unpack VALU under the
+    // MFMAs; both leave the K-step time unchanged or worse.)
+    auto mfma4 = [&](const uint4 b, const uint8_t * stage, int slot) {
+        const uint4 a0 = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(r, slot));
+        const uint4 a1 = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(32 + r, slot));
+        const uint4 a2 = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(64 + r, slot));
+        const uint4 a3 = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(96 + r, slot));
+        const f16x8 bb = *reinterpret_cast<const f16x8 *>(&b);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a0), bb, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a1), bb, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a2), bb, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a3), bb, acc[3], 0, 0, 0);
+    };
+    auto compute = [&](const RegbFrag fr, const uint8_t * stage) {
+        mfma4(fr.f0, stage, 0 + h);
+        mfma4(fr.f1, stage, 2 + h);
+        mfma4(fr.f2, stage, 4 + h);
+        mfma4(fr.f3, stage, 6 + h);
+    };
+
+    // software pipeline: weight bytes two K-steps ahead in registers (even/odd slots), header one block ahead,
+    // activation chunks two K-steps ahead in registers and one K-step ahead in LDS
+    uint4 q_e = load_qs(0), q_o = load_qs(1);
+    uint4 hdr = load_hdr(0), hdr_n = load_hdr(1);
+    XRegs x_e = load_x(0), x_o = load_x(1);
+    store_x(x_e, lds);
+    x_e = load_x(2);
+    __syncthreads();
+
+    for (int kb = 0; kb < nblk; ++kb) {                       // one Q4_K block (256 k) = four K-steps, j = 0..3
+        const int ks = 4 * kb;
+        RegbFrag fr;
+        // j = 0 (even): stage buffer 0
+        fr = regb_unpack_q4k(q_e, hdr, 0);
+        q_e = load_qs(ks + 2);
+        store_x(x_o, lds + STAGE);  x_o = load_x(ks + 3);
+        compute(fr, lds);
+        __syncthreads();
+        // j = 1 (odd): stage buffer 1
+        fr = regb_unpack_q4k(q_o, hdr, 1);
+        q_o = load_qs(ks + 3);
+        store_x(x_e, lds);          x_e = load_x(ks + 4);
+        compute(fr, lds + STAGE);
+        __syncthreads();
+        // j = 2
+        fr = regb_unpack_q4k(q_e, hdr, 2);
+        q_e = load_qs(ks + 4);
+        store_x(x_o, lds + STAGE);  x_o = load_x(ks + 5);
+        compute(fr, lds);
+        __syncthreads();
+        // j = 3
+        fr = regb_unpack_q4k(q_o, hdr, 3);
+        q_o = load_qs(ks + 5);
+        hdr = hdr_n;
+        hdr_n = load_hdr(kb + 2);
+        store_x(x_e, lds);          x_e = load_x(ks + 6);
+        compute(fr, lds + STAGE);
+        __syncthreads();
+    }
+
+    // epilogue: per-token scales / dst row offsets staged through LDS (all reads of the tiles are behind the last barrier)
+    float *   sc_lds  = reinterpret_cast<float *>(lds);
+    int64_t * off_lds = reinterpret_cast<int64_t *>(lds + 1024);
+    if (tid < BN) {
+        const int t = tok0 + tid;
+        const bool live = t < segn;
+        sc_lds[tid]  = live ? scale[seg0 + t] : 0.0f;
+        off_lds[tid] = live ? (dst_off ? dst_off[seg0 + t] : (int64_t) t * ldd) : 0;
+    }
+    __syncthreads();
+    const int m = row0 + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int tl = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (tok0 + tl < segn && m < M) dst[off_lds[tl] + m] = acc[i][e] * sc_lds[tl];
+        }
+}
+
+inline int launch_mfma_regb_q4k(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
+                                const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
+                                float * dst, int64_t ldd, const int64_t * dst_off) {
+    // 256-row tiles (8 waves: two per SIMD) unless that leaves most CUs without a workgroup
+    const bool small = (int64_t) ((M + 255) / 256) * n_tiles_y * n_expert < c->cus;
+    if (small)
+        hipLaunchKernelGGL((mfma_regb_q4k_kernel<4>), dim3((M + 127) / 128, n_tiles_y, n_expert), dim3(256), 0, st, (const uint8_t *) W, rb, eb,
+                           M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off);
+    else
+        hipLaunchKernelGGL((mfma_regb_q4k_kernel<8>), dim3((M + 255) / 256, n_tiles_y, n_expert), dim3(512), 0, st, (const uint8_t *) W, rb, eb,
+                           M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+} // namespace qmm
