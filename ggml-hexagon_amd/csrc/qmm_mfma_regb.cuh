@@ -47,13 +47,13 @@ __device__ __forceinline__ RegbFrag regb_unpack_q4k(const uint4 qs, const uint4 
     return fr;
 }
 
-template <int NW>       // waves per workgroup: tile = 32*NW weight rows x 128 tokens
+template <int NW, int BN>   // waves per workgroup, tokens per tile: tile = 32*NW weight rows x BN tokens
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64_t expert_bytes, const int M, const int K,
                      const uint16_t * __restrict__ Xh, const int Kp, const float * __restrict__ scale,
                      const int * __restrict__ seg_start, const int * __restrict__ seg_count, const int N,
                      float * __restrict__ dst, const int64_t ldd, const int64_t * __restrict__ dst_off) {
-    constexpr int BN = 128, BK = 64, ROWB = BK * 2, SLOTS = 8;
+    constexpr int BK = 64, ROWB = BK * 2, SLOTS = 8, NA = BN / 32;
     constexpr int NT = NW * 64;
     constexpr int X_CHUNKS = BN * SLOTS / NT;                 // 16-byte chunks of the activation tile per thread per K-step
     constexpr int STAGE = BN * ROWB;                          // 16 KB
@@ -75,9 +75,9 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
                            (size_t) (tid / SLOTS) * Kp * 2 + (tid % SLOTS) * 16;
     const int xrow_step = (NT / SLOTS) * Kp * 2;
 
-    f32x16 acc[4];
+    f32x16 acc[NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
 
@@ -103,15 +103,13 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
     // pinning 8 reads ahead of the MFMAs with sched_group_barrier; interleaving the next K-step's unpack VALU under the
     // MFMAs; both leave the K-step time unchanged or worse.)
     auto mfma4 = [&](const uint4 b, const uint8_t * stage, int slot) {
-        const uint4 a0 = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(r, slot));
-        const uint4 a1 = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(32 + r, slot));
-        const uint4 a2 = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(64 + r, slot));
-        const uint4 a3 = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(96 + r, slot));
+        uint4 a[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[i] = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(32 * i + r, slot));
         const f16x8 bb = *reinterpret_cast<const f16x8 *>(&b);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a0), bb, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a1), bb, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a2), bb, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a3), bb, acc[3], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a[i]), bb, acc[i], 0, 0, 0);
     };
     auto compute = [&](const RegbFrag fr, const uint8_t * stage) {
         mfma4(fr.f0, stage, 0 + h);
@@ -172,7 +170,7 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
     __syncthreads();
     const int m = row0 + r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int tl = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -183,14 +181,19 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
 inline int launch_mfma_regb_q4k(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
                                 const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
                                 float * dst, int64_t ldd, const int64_t * dst_off) {
-    // 256-row tiles (8 waves: two per SIMD) unless that leaves most CUs without a workgroup
-    const bool small = (int64_t) ((M + 255) / 256) * n_tiles_y * n_expert < c->cus;
-    if (small)
-        hipLaunchKernelGGL((mfma_regb_q4k_kernel<4>), dim3((M + 127) / 128, n_tiles_y, n_expert), dim3(256), 0, st, (const uint8_t *) W, rb, eb,
-                           M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off);
-    else
-        hipLaunchKernelGGL((mfma_regb_q4k_kernel<8>), dim3((M + 255) / 256, n_tiles_y, n_expert), dim3(512), 0, st, (const uint8_t *) W, rb, eb,
-                           M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off);
+    // tile choice = chip fill: 256 rows x 128 tokens (8 waves, two per SIMD) when that gives (almost) every CU a workgroup,
+    // else 128 x 128, else 128 x 64 / 128 x 32 (the weight unpack is then repeated 2x / 4x, on CUs that would otherwise idle).
+    // n_tiles_y counts 128-token tiles of the (worst-case) token range.
+    const int64_t wg_256 = (int64_t) ((M + 255) / 256) * n_tiles_y * n_expert;
+    const int64_t wg_128 = (int64_t) ((M + 127) / 128) * n_tiles_y * n_expert;
+#define QMM_REGB(NWv, BNv, ROWS, TY)                                                                                                \
+    hipLaunchKernelGGL((mfma_regb_q4k_kernel<NWv, BNv>), dim3((M + ROWS - 1) / ROWS, TY, n_expert), dim3(NWv * 64), 0, st,          \
+                       (const uint8_t *) W, rb, eb, M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off)
+    if (wg_256 * 10 >= (int64_t) c->cus * 8) QMM_REGB(8, 128, 256, n_tiles_y);
+    else if (wg_128 >= c->cus)              QMM_REGB(4, 128, 128, n_tiles_y);
+    else if (2 * wg_128 >= c->cus / 2)       QMM_REGB(4, 64, 128, 2 * n_tiles_y);
+    else                                     QMM_REGB(4, 32, 128, 4 * n_tiles_y);
+#undef QMM_REGB
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }
