@@ -64,8 +64,8 @@ template <bool F16> __device__ __forceinline__ uint32_t pack16(float a, float b)
 // PERM: the k-order in which the operand row is stored; MFMA sums over k, so any order shared by both operands is fine.
 //   0  natural
 //   1  every aligned group of four k as (0, 2, 1, 3): the order the packed-f16 unpacks (unpack_q6k_f16) produce
-//   2  per 64-block, position p = kk*16 + h*8 + e holds k = (kk&1)*8 + 16h + 32*(kk>>1) + (0,2,1,3,4,6,5,7)[e]: the order in
-//      which a lane of qmm_mfma_regb.cuh owns its 16 bytes of a Q4_K sub-block pair (h = lane half, kk = MFMA k-step)
+//   2, 3, 4  the lane-ownership orders of the register-B kernels for Q4_K, Q6_K, Q4_0 (table in qmm_mfma_regb.cuh):
+//      position p = kk*16 + h*8 + e of a 64- (Q6_K: 128-) block holds k = f(kk, h) + (0,2,1,3,4,6,5,7)[e]
 template <int ACT, bool F16Q8, int PERM>
 __global__ void __launch_bounds__(256)
 prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t * __restrict__ gather,
@@ -111,12 +111,18 @@ prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t *
     const float inv = mx > 0.0f ? 1.0f / mx : 0.0f;
     for (int k = tid * 8; k < Kp; k += 256 * 8) {
         uint4 o = make_uint4(0, 0, 0, 0);
-        if (k < K) {
-            int ksrc = k;
-            if (PERM == 2) {
-                const int p = k & 63, kk = p >> 4, h = (p >> 3) & 1;
-                ksrc = (k & ~63) + (kk & 1) * 8 + 16 * h + 32 * (kk >> 1);
-            }
+        int ksrc = k;                                        // where this group of 8 output positions comes from
+        if (PERM == 2) {
+            const int p = k & 63, kk = p >> 4, h = (p >> 3) & 1;
+            ksrc = (k & ~63) + (kk & 1) * 8 + 16 * h + 32 * (kk >> 1);
+        } else if (PERM == 4) {
+            const int p = k & 63, kk = p >> 4, h = (p >> 3) & 1;
+            ksrc = (k & ~63) + 32 * h + (kk & 1) * 8 + 16 * (kk >> 1);
+        } else if (PERM == 3) {
+            const int p = k & 127, kk = p >> 4, h = (p >> 3) & 1;
+            ksrc = (k & ~127) + 32 * (kk >> 1) + 16 * h + 8 * (kk & 1);
+        }
+        if (ksrc < K) {                                      // K need not be a multiple of the permutation block (Q4_0: K % 32)
             const float t = ad[ksrc / QB] * inv;             // |t| <= 1
             const int2 qq = *reinterpret_cast<const int2 *>(aq + ksrc);
             float v[8];
@@ -199,8 +205,9 @@ __device__ __forceinline__ void unpack_q6k_f16(const Unit<T_Q6_K> & wu, int g, u
 }
 
 template <int T, bool F16> struct MfmaPerm4 { static constexpr bool value = false; };
-template <> struct MfmaPerm4<T_Q4_K, true> { static constexpr bool value = true; };
-template <> struct MfmaPerm4<T_Q6_K, true> { static constexpr bool value = true; };
+// (Q4_K / Q6_K / Q4_0 in F16 mode run the register-B kernels of qmm_mfma_regb.cuh; this LDS-tile kernel serves Q5_K, Q8_0 and
+//  the bf16 mode with the bit-exact to_f32 unpack in natural k order.  The packed unpacks above remain available: switch a type
+//  to `true` here together with PERM 1 in launch_prep.)
 
 // ------------------------------------------------------------------------------------------------
 // stage 2.  Wave-specialized workgroup of 8 waves (512 threads) per BN x BM tile of dst:
@@ -431,18 +438,19 @@ template <int ACT>
 inline int launch_prep(qmm_ctx * c, hipStream_t st, int type, const float * x, int64_t ldx, const int64_t * gather, const int * n_dev,
                        int n_rows, int n_pad, int K, int Kp, uint16_t * xh, float * scale) {
     const size_t lds = (size_t) K + (size_t) (K / 32) * 4 + 64;
-    if (c->prec == QMM_PREC_F16_Q8 && type == T_Q4_K)          // register-B kernel's lane order (qmm_mfma_regb.cuh)
-        hipLaunchKernelGGL((prep_act_kernel<ACT, true, 2>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
-                           c->act_mode, xh, scale);
-    else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q6_K)     // packed-f16 unpack order
-        hipLaunchKernelGGL((prep_act_kernel<ACT, true, 1>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
-                           c->act_mode, xh, scale);
+#define QMM_PREP(PERMv)                                                                                                            \
+    hipLaunchKernelGGL((prep_act_kernel<ACT, true, PERMv>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,     \
+                       c->act_mode, xh, scale)
+    if (c->prec == QMM_PREC_F16_Q8 && type == T_Q4_K)      QMM_PREP(2);      // register-B lane orders (qmm_mfma_regb.cuh)
+    else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q6_K) QMM_PREP(3);
+    else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q4_0) QMM_PREP(4);
     else if (c->prec == QMM_PREC_F16_Q8)
         hipLaunchKernelGGL((prep_act_kernel<ACT, true, 0>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
                            c->act_mode, xh, scale);
     else
         hipLaunchKernelGGL((prep_act_kernel<ACT, false, 0>), dim3(n_pad), dim3(256), 0, st, x, ldx, gather, n_dev, n_rows, K, Kp,
                            c->act_mode, xh, scale);
+#undef QMM_PREP
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }
@@ -470,15 +478,16 @@ inline int launch_mfma(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, 
     return QMM_OK;
 }
 
-int launch_mfma_regb_q4k(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
-                         const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
-                         float * dst, int64_t ldd, const int64_t * dst_off);
+bool mfma_regb_supports(const qmm_ctx * c, int type);
+int  launch_mfma_regb(qmm_ctx * c, hipStream_t st, int type, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
+                      const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
+                      float * dst, int64_t ldd, const int64_t * dst_off);
 
 inline int launch_mfma_any(qmm_ctx * c, hipStream_t st, int type, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
                            const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
                            float * dst, int64_t ldd, const int64_t * dst_off) {
-    if (type == T_Q4_K && c->prec == QMM_PREC_F16_Q8)
-        return launch_mfma_regb_q4k(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
+    if (mfma_regb_supports(c, type))
+        return launch_mfma_regb(c, st, type, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
     switch (type) {
         case T_Q4_0: return launch_mfma<T_Q4_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
         case T_Q8_0: return launch_mfma<T_Q8_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
@@ -491,7 +500,7 @@ inline int launch_mfma_any(qmm_ctx * c, hipStream_t st, int type, const void * W
 // what the prepared operand depends on besides src1 itself: Q8_0 vs Q8_K emulation and the k-order of the unpack
 inline int mfma_prep_key(const qmm_ctx * c, int type) {
     if (c->prec != QMM_PREC_F16_Q8) return 0;
-    return 1 + ((type == T_Q4_0 || type == T_Q8_0) ? 1 : 0) + (type == T_Q4_K ? 2 : 0) + (type == T_Q6_K ? 4 : 0);
+    return 1 + type;      // activation format (Q8_0 / Q8_K emulation) and k-order both follow from the weight type
 }
 
 // plain MUL_MAT, N > 8.  `reuse_prep`: the previous call of a group already prepared the same src1 with the same key.
