@@ -64,7 +64,7 @@ template <bool F16> __device__ __forceinline__ uint32_t pack16(float a, float b)
 // PERM: the k-order in which the operand row is stored; MFMA sums over k, so any order shared by both operands is fine.
 //   0  natural
 //   1  every aligned group of four k as (0, 2, 1, 3): the order the packed-f16 unpacks (unpack_q6k_f16) produce
-//   2, 3, 4  the lane-ownership orders of the register-B kernels for Q4_K, Q6_K, Q4_0 (table in qmm_mfma_regb.cuh):
+//   2, 3, 4, 5  the lane-ownership orders of the register-B kernels for Q4_K/Q5_K, Q6_K, Q4_0, Q8_0 (table in qmm_mfma_regb.cuh):
 //      position p = kk*16 + h*8 + e of a 64- (Q6_K: 128-) block holds k = f(kk, h) + (0,2,1,3,4,6,5,7)[e]
 template <int ACT, bool F16Q8, int PERM>
 __global__ void __launch_bounds__(256)
@@ -118,6 +118,9 @@ prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t *
         } else if (PERM == 4) {
             const int p = k & 63, kk = p >> 4, h = (p >> 3) & 1;
             ksrc = (k & ~63) + 32 * h + (kk & 1) * 8 + 16 * (kk >> 1);
+        } else if (PERM == 5) {
+            const int p = k & 63, kk = p >> 4, h = (p >> 3) & 1;
+            ksrc = (k & ~63) + 32 * h + 8 * kk;
         } else if (PERM == 3) {
             const int p = k & 127, kk = p >> 4, h = (p >> 3) & 1;
             ksrc = (k & ~127) + 32 * (kk >> 1) + 16 * h + 8 * (kk & 1);
@@ -441,7 +444,8 @@ inline int launch_prep(qmm_ctx * c, hipStream_t st, int type, const float * x, i
 #define QMM_PREP(PERMv)                                                                                                            \
     hipLaunchKernelGGL((prep_act_kernel<ACT, true, PERMv>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,     \
                        c->act_mode, xh, scale)
-    if (c->prec == QMM_PREC_F16_Q8 && type == T_Q4_K)      QMM_PREP(2);      // register-B lane orders (qmm_mfma_regb.cuh)
+    if (c->prec == QMM_PREC_F16_Q8 && (type == T_Q4_K || type == T_Q5_K)) QMM_PREP(2);      // register-B lane orders (qmm_mfma_regb.cuh)
+    else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q8_0) QMM_PREP(5);
     else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q6_K) QMM_PREP(3);
     else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q4_0) QMM_PREP(4);
     else if (c->prec == QMM_PREC_F16_Q8)
@@ -500,7 +504,7 @@ inline int launch_mfma_any(qmm_ctx * c, hipStream_t st, int type, const void * W
 // what the prepared operand depends on besides src1 itself: Q8_0 vs Q8_K emulation and the k-order of the unpack
 inline int mfma_prep_key(const qmm_ctx * c, int type) {
     if (c->prec != QMM_PREC_F16_Q8) return 0;
-    return 1 + type;      // activation format (Q8_0 / Q8_K emulation) and k-order both follow from the weight type
+    return 1 + (type == T_Q5_K ? T_Q4_K : type);      // activation format and k-order follow from the weight type (Q5_K shares Q4_K's)
 }
 
 // plain MUL_MAT, N > 8.  `reuse_prep`: the previous call of a group already prepared the same src1 with the same key.

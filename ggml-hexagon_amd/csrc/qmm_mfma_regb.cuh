@@ -1,4 +1,4 @@
-// qmm_mfma_regb.cuh — prefill kernel, "register-B" form (QMM_PREC_F16_Q8; Q4_K, Q6_K, Q4_0).
+// qmm_mfma_regb.cuh — prefill kernel, "register-B" form (QMM_PREC_F16_Q8, all five weight types).
 //
 // Every wave owns 32 weight rows and ALL tokens of the tile.  A lane (row r = lane & 31, half h = lane >> 5) owns a fixed
 // slice of the quant bytes of its row's current K-step: it loads them straight from HBM (16-byte loads), unpacks them
@@ -11,6 +11,8 @@
 //   type  BK   lane's bytes per K-step                        MFMA k-step kk holds, for half h, k =            prep PERM
 //   Q4_K  64   16 of the pair's 32 qs bytes (+ header)        (kk&1)*8 + 16h + 32*(kk>>1) + e'                 2
 //   Q4_0  64   block h of the two: d + 16 qs bytes            32h + (kk&1)*8 + 16*(kk>>1) + e'                 4
+//   Q5_K  64   as Q4_K + the 16 qh bytes of the same l        as Q4_K                                          2
+//   Q8_0  64   block h of the two: d + 32 int8                32h + 8*kk + e'                                  5
 //   Q6_K  128  16 ql[l], 16 ql[l+32], 16 qh[l], l = 16h..     32*(kk>>1) + 16h + 8*(kk&1) + e'                 3
 //   with e' = (0,2,1,3,4,6,5,7)[e]: the packed unpack emits byte pairs (0,2), (1,3).
 //
@@ -94,6 +96,76 @@ template <> struct Regb<T_Q4_0> {
         f[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
         f[2] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         f[3] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+    }
+};
+
+// ---- Q5_K: Q4_K plus one high bit per weight from qh[l] (bit 2j for the low-nibble run, 2j+1 for the high-nibble run) ------
+template <> struct Regb<T_Q5_K> {
+    static constexpr int BK = 64, NFRAG = 4, PERM = 2;
+    struct Raw { uint4 qs, qh, hdr; };
+    static __device__ __forceinline__ Raw load(const uint8_t * wrow, int ks, int h, int K) {
+        const int k2 = min(ks, K / 64 - 1);
+        const uint8_t * blk = wrow + (size_t) (k2 >> 2) * 176;
+        Raw r;
+        r.hdr = ldg<uint4>(blk);
+        r.qh  = ldg<uint4>(blk + 16 + 16 * h);
+        r.qs  = ldg<uint4>(blk + 48 + 32 * (k2 & 3) + 16 * h);
+        if (ks > k2) r.hdr.x = 0;
+        return r;
+    }
+    static __device__ __forceinline__ void unpack(const Raw & w, int ks, uint4 (&f)[4]) {
+        const int j = ks & 3;
+        uint32_t sc, mn;
+        k4_pair(w.hdr, j, sc, mn);
+        const float d = h2f(w.hdr.x & 0xffff), dmin = h2f(w.hdr.x >> 16);
+        const _Float16 ds0 = (_Float16) (d * (float) (sc & 0xff)), ds1 = (_Float16) (d * (float) (sc >> 8));
+        const _Float16 no0 = (_Float16) (-(dmin * (float) (mn & 0xff))), no1 = (_Float16) (-(dmin * (float) (mn >> 8)));
+        const f16x2 DS0 = { ds0, ds0 }, DS1 = { ds1, ds1 }, NO0 = { no0, no0 }, NO1 = { no1, no1 };
+        const f16x2 BIAS = { (_Float16) -1024.0f, (_Float16) -1024.0f };
+        const uint32_t q[4] = { w.qs.x, w.qs.y, w.qs.z, w.qs.w }, g[4] = { w.qh.x, w.qh.y, w.qh.z, w.qh.w };
+        const uint32_t ONE = 0x00010001u;
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t gl = g[i] >> (2 * j), gh = g[i] >> (2 * j + 1);
+            lo[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2((q[i] & RB_M4) | ((gl & ONE) << 4) | RB_E) + BIAS, DS0, NO0));
+            lo[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 8) & RB_M4) | (((gl >> 8) & ONE) << 4) | RB_E) + BIAS, DS0, NO0));
+            hi[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 4) & RB_M4) | ((gh & ONE) << 4) | RB_E) + BIAS, DS1, NO1));
+            hi[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 12) & RB_M4) | (((gh >> 8) & ONE) << 4) | RB_E) + BIAS, DS1, NO1));
+        }
+        f[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        f[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+        f[2] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        f[3] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+    }
+};
+
+// ---- Q8_0: int8 b -> f16 through (b ^ 0x80) | 0x6400 = 1024 + 128 + b; value = b * d with d an f16: one rounding ---------
+template <> struct Regb<T_Q8_0> {
+    static constexpr int BK = 64, NFRAG = 4, PERM = 5;
+    struct Raw { uint4 q0, q1; uint32_t d; };
+    static __device__ __forceinline__ Raw load(const uint8_t * wrow, int ks, int h, int K) {
+        const int b = 2 * ks + h, bc = min(b, K / 32 - 1);
+        const uint8_t * blk = wrow + (size_t) bc * 34;
+        Raw r;
+        r.d  = b > bc ? 0u : (uint32_t) ldg<uint16_t>(blk);
+        r.q0 = ldg<uint4>(blk + 2);
+        r.q1 = ldg<uint4>(blk + 18);
+        return r;
+    }
+    static __device__ __forceinline__ void unpack(const Raw & w, int, uint4 (&f)[4]) {
+        const _Float16 d = __builtin_bit_cast(_Float16, (unsigned short) w.d);
+        const f16x2 D = { d, d }, BIAS = { (_Float16) -1152.0f, (_Float16) -1152.0f };
+        const uint32_t q[8] = { w.q0.x, w.q0.y, w.q0.z, w.q0.w, w.q1.x, w.q1.y, w.q1.z, w.q1.w };
+        uint32_t o[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t u = q[i] ^ 0x80808080u;
+            o[2 * i]     = h2_bits((bits_h2((u & RB_M8) | RB_E) + BIAS) * D);            // bytes 4i, 4i+2
+            o[2 * i + 1] = h2_bits((bits_h2(((u >> 8) & RB_M8) | RB_E) + BIAS) * D);     // bytes 4i+1, 4i+3
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) f[kk] = make_uint4(o[4 * kk], o[4 * kk + 1], o[4 * kk + 2], o[4 * kk + 3]);
     }
 };
 
@@ -421,7 +493,7 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
 }
 
 inline bool mfma_regb_supports(const qmm_ctx * c, int type) {
-    return c->prec == QMM_PREC_F16_Q8 && (type == T_Q4_K || type == T_Q6_K || type == T_Q4_0);
+    return c->prec == QMM_PREC_F16_Q8 && (type == T_Q4_K || type == T_Q5_K || type == T_Q6_K || type == T_Q4_0 || type == T_Q8_0);
 }
 
 template <int T>
@@ -454,6 +526,8 @@ inline int launch_mfma_regb(qmm_ctx * c, hipStream_t st, int type, const void * 
                             float * dst, int64_t ldd, const int64_t * dst_off) {
     switch (type) {
         case T_Q4_K: return launch_mfma_regb_t<T_Q4_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
+        case T_Q5_K: return launch_mfma_regb_t<T_Q5_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
+        case T_Q8_0: return launch_mfma_regb_t<T_Q8_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
         case T_Q6_K: return launch_mfma_regb_t<T_Q6_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
         default:     return launch_mfma_regb_t<T_Q4_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
     }
