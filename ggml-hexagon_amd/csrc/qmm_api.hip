@@ -125,6 +125,10 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->act_mode = atoi(e) ? QMM_ACT_X86 : QMM_ACT_REF;
     e = getenv("GGML_MI355X_MV_BPC");
     if (e && atoi(e) >= 1 && atoi(e) <= 8) c->mv_bpc = atoi(e);
+    e = getenv("GGML_MI355X_SKINNY");
+    if (e) c->skinny = atoi(e);
+    e = getenv("GGML_MI355X_SKINNY_MAXN");
+    if (e && atoi(e) >= 9) c->skinny_max_n = c->skinny_max_n_few = atoi(e);
     e = getenv("GGML_MI355X_ABLATE");
     if (e) { int v = atoi(e); (void) hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_dbg), &v, sizeof(int)); }
     e = getenv("GGML_MI355X_PREC");
@@ -309,7 +313,7 @@ int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, con
     int last_key = -1;                   // the group shares src1: its 16-bit operand is prepared once per activation format
     for (int i = 0; i < nw; ++i) {
         if (ws[i].M == 0) continue;
-        const int key = mfma_prep_key(c, ws[i].type);
+        const int key = mfma_prep_key(c, ws[i].type, N, ws[i].M);
         int rc = mfma_mul_mat(c, st, ws[i].type, ws[i].w, ws[i].w_row_bytes, K, ws[i].M, x, N, ldx, ws[i].dst, ws[i].ldd, key == last_key);
         if (rc) return rc;
         last_key = key;

@@ -57,6 +57,13 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 }
 template <bool F16> __device__ __forceinline__ uint32_t pack16(float a, float b) { return F16 ? pack_f16(a, b) : pack_bf16(a, b); }
 
+// fragment-major operand layout: index (in 16-byte chunks) of the chunk holding positions k..k+7 of token row `row`.
+// A K-step is BKP positions = BKP/16 MFMA k-steps; chunk (kk, h) of a row belongs to lane h*32 + row%32 of its 32-token tile.
+__device__ __forceinline__ int64_t frag_major_chunk(int row, int k, int Kp, int BKP) {
+    const int ks = k / BKP, p = k % BKP, kk = p >> 4, h = (p >> 3) & 1;
+    return (((int64_t) (row >> 5) * (Kp / BKP) + ks) * (BKP / 16) + kk) * 64 + h * 32 + (row & 31);
+}
+
 // ------------------------------------------------------------------------------------------------
 // stage 1: activation rows -> MFMA operand rows.  One workgroup per output row.
 //   src row r: x + gather(r)   (gather == nullptr: r*ldx; MoE: element offset of the pair's src1 row)
@@ -70,14 +77,20 @@ template <int ACT, bool F16Q8, int PERM>
 __global__ void __launch_bounds__(256)
 prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t * __restrict__ gather,
                 const int * __restrict__ n_rows_dev, const int n_rows, const int K, const int Kp, const int act_mode,
-                uint16_t * __restrict__ xh, float * __restrict__ scale) {
+                const int frag_major, uint16_t * __restrict__ xh, float * __restrict__ scale) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int r = blockIdx.x;
     const int tid = threadIdx.x;
     const int live_rows = n_rows_dev ? *n_rows_dev : n_rows;
-    uint16_t * out = xh + (int64_t) r * Kp;
+    // where the 8 values of output position k (multiple of 8) of this row go: row-major Xh[r][k], or fragment-major
+    // (few-token kernel): the 64 lanes' 16-byte A-fragment chunks of one (32-token tile, K-step, 16-deep k-step) contiguous
+    constexpr int BKP = PERM == 3 ? 128 : 64;
+    auto out_at = [&](int k) -> uint4 * {
+        if (!frag_major) return reinterpret_cast<uint4 *>(xh + (int64_t) r * Kp + k);
+        return reinterpret_cast<uint4 *>(xh) + frag_major_chunk(r, k, Kp, BKP);
+    };
     if (r >= live_rows) {                                   // padding rows: zeros
-        for (int k = tid * 8; k < Kp; k += 256 * 8) *reinterpret_cast<uint4 *>(out + k) = make_uint4(0, 0, 0, 0);
+        for (int k = tid * 8; k < Kp; k += 256 * 8) *out_at(k) = make_uint4(0, 0, 0, 0);
         if (tid == 0) scale[r] = 0.0f;
         return;
     }
@@ -90,7 +103,7 @@ prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t *
                 const float4 b = *reinterpret_cast<const float4 *>(src + k + 4);
                 o = make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
             }
-            *reinterpret_cast<uint4 *>(out + k) = o;
+            *out_at(k) = o;
         }
         if (tid == 0) scale[r] = 1.0f;
         return;
@@ -137,7 +150,7 @@ prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t *
             o = PERM ? make_uint4(pack_f16(v[0], v[2]), pack_f16(v[1], v[3]), pack_f16(v[4], v[6]), pack_f16(v[5], v[7]))
                       : make_uint4(pack_f16(v[0], v[1]), pack_f16(v[2], v[3]), pack_f16(v[4], v[5]), pack_f16(v[6], v[7]));
         }
-        *reinterpret_cast<uint4 *>(out + k) = o;
+        *out_at(k) = o;
     }
     if (tid == 0) scale[r] = mx;
 }
@@ -435,25 +448,26 @@ struct MfmaOperand {            // a prepared activation matrix in the workspace
     const uint16_t * xh;
     const float *    scale;
     int              Kp;
+    int              frag_major;   // layout of xh: 0 = rows of Kp, 1 = fragment-major (frag_major_chunk)
 };
 
 template <int ACT>
 inline int launch_prep(qmm_ctx * c, hipStream_t st, int type, const float * x, int64_t ldx, const int64_t * gather, const int * n_dev,
-                       int n_rows, int n_pad, int K, int Kp, uint16_t * xh, float * scale) {
+                       int n_rows, int n_pad, int K, int Kp, int frag_major, uint16_t * xh, float * scale) {
     const size_t lds = (size_t) K + (size_t) (K / 32) * 4 + 64;
 #define QMM_PREP(PERMv)                                                                                                            \
     hipLaunchKernelGGL((prep_act_kernel<ACT, true, PERMv>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,     \
-                       c->act_mode, xh, scale)
+                       c->act_mode, frag_major, xh, scale)
     if (c->prec == QMM_PREC_F16_Q8 && (type == T_Q4_K || type == T_Q5_K)) QMM_PREP(2);      // register-B lane orders (qmm_mfma_regb.cuh)
     else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q8_0) QMM_PREP(5);
     else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q6_K) QMM_PREP(3);
     else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q4_0) QMM_PREP(4);
     else if (c->prec == QMM_PREC_F16_Q8)
         hipLaunchKernelGGL((prep_act_kernel<ACT, true, 0>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
-                           c->act_mode, xh, scale);
+                           c->act_mode, frag_major, xh, scale);
     else
         hipLaunchKernelGGL((prep_act_kernel<ACT, false, 0>), dim3(n_pad), dim3(256), 0, st, x, ldx, gather, n_dev, n_rows, K, Kp,
-                           c->act_mode, xh, scale);
+                           c->act_mode, frag_major, xh, scale);
 #undef QMM_PREP
     HIP_TRY(hipGetLastError());
     return QMM_OK;
@@ -483,6 +497,13 @@ inline int launch_mfma(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, 
 }
 
 bool mfma_regb_supports(const qmm_ctx * c, int type);
+// few tokens: the split-K kernel of qmm_mfma_regb.cuh, which wants the operand fragment-major
+// (measured on MI355X: it wins up to 64 tokens on any matrix, and up to 256 tokens on matrices of <= 8192 rows, which give
+// the tiled kernels too few workgroups to fill the chip)
+inline bool mfma_use_skinny(const qmm_ctx * c, int type, int64_t N, int64_t M, int64_t n_expert = 1) {
+    if (!mfma_regb_supports(c, type) || !c->skinny) return false;
+    return N <= c->skinny_max_n || (N <= c->skinny_max_n_few && (M + 31) / 32 * n_expert <= c->cus);
+}
 int  launch_mfma_regb(qmm_ctx * c, hipStream_t st, int type, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
                       const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
                       float * dst, int64_t ldd, const int64_t * dst_off);
@@ -502,9 +523,10 @@ inline int launch_mfma_any(qmm_ctx * c, hipStream_t st, int type, const void * W
 }
 
 // what the prepared operand depends on besides src1 itself: Q8_0 vs Q8_K emulation and the k-order of the unpack
-inline int mfma_prep_key(const qmm_ctx * c, int type) {
+inline int mfma_prep_key(const qmm_ctx * c, int type, int64_t N, int64_t M) {
     if (c->prec != QMM_PREC_F16_Q8) return 0;
-    return 1 + (type == T_Q5_K ? T_Q4_K : type);      // activation format and k-order follow from the weight type (Q5_K shares Q4_K's)
+    // activation format and k-order follow from the weight type (Q5_K shares Q4_K's); the layout from the kernel choice
+    return 2 * (1 + (type == T_Q5_K ? T_Q4_K : type)) + (mfma_use_skinny(c, type, N, M) ? 1 : 0);
 }
 
 // plain MUL_MAT, N > 8.  `reuse_prep`: the previous call of a group already prepared the same src1 with the same key.
@@ -518,12 +540,13 @@ inline int mfma_mul_mat(qmm_ctx * c, hipStream_t st, int type, const void * W, i
     uint16_t * xh = (uint16_t *) c->ws;
     float * scale = (float *) ((uint8_t *) c->ws + xh_bytes);
     const bool q8_0 = (type == T_Q4_0 || type == T_Q8_0);
+    const int frag = mfma_use_skinny(c, type, N, M);
     if (!reuse_prep) {           // the caller guarantees: same src1, same activation format and k-order as the previous call
-        rc = q8_0 ? launch_prep<T_Q8_0>(c, st, type, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, xh, scale)
-                  : launch_prep<T_Q8_K>(c, st, type, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, xh, scale);
+        rc = q8_0 ? launch_prep<T_Q8_0>(c, st, type, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, frag, xh, scale)
+                  : launch_prep<T_Q8_K>(c, st, type, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, frag, xh, scale);
         if (rc) return rc;
     }
-    MfmaOperand op = { xh, scale, Kp };
+    MfmaOperand op = { xh, scale, Kp, frag };
     return launch_mfma_any(c, st, type, W, rb, 0, 1, (int) M, (int) K, op, nullptr, nullptr, (int) N, Np / 128, dst, ldd, nullptr);
 }
 

@@ -190,30 +190,39 @@ template <> struct Regb<T_Q6_K> {
         const uint32_t v = i < 4 ? w.sc8.x : w.sc8.y;
         return (int) (int8_t) ((v >> ((i & 3) * 8)) & 0xff);
     }
-    static __device__ __forceinline__ void unpack_h(const Raw & w, int h, uint4 (&f)[8]) {
+    // fragments 4*HF .. 4*HF+3 (sub-blocks rr = 2*HF, 2*HF+1 of the lane's four): HF = 0 low nibbles, HF = 1 high nibbles
+    template <int HF>
+    static __device__ __forceinline__ void unpack_half(const Raw & w, int h, uint4 (&f)[4]) {
         const float d = h2f(w.d);
         const f16x2 BIAS = { (_Float16) -1056.0f, (_Float16) -1056.0f };
         const uint32_t A[4] = { w.qa.x, w.qa.y, w.qa.z, w.qa.w }, B[4] = { w.qb.x, w.qb.y, w.qb.z, w.qb.w },
                        H[4] = { w.qh.x, w.qh.y, w.qh.z, w.qh.w };
-        uint32_t o[4][8];
+        uint32_t o[2][8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t m4 = 0x0f0f0f0fu, m2 = 0x30303030u;
-            const uint32_t v[4] = { (A[i] & m4) | ((H[i] << 4) & m2), (B[i] & m4) | ((H[i] << 2) & m2),
-                                    ((A[i] >> 4) & m4) | (H[i] & m2), ((B[i] >> 4) & m4) | ((H[i] >> 2) & m2) };
+            const uint32_t v[2] = { HF == 0 ? (A[i] & m4) | ((H[i] << 4) & m2) : ((A[i] >> 4) & m4) | (H[i] & m2),
+                                    HF == 0 ? (B[i] & m4) | ((H[i] << 2) & m2) : ((B[i] >> 4) & m4) | ((H[i] >> 2) & m2) };
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const _Float16 t = (_Float16) (d * (float) scale(w, h, rr));
+            for (int q = 0; q < 2; ++q) {
+                const _Float16 t = (_Float16) (d * (float) scale(w, h, 2 * HF + q));
                 const f16x2 DS = { t, t };
-                o[rr][2 * i]     = h2_bits((bits_h2((v[rr] & RB_M8) | RB_E) + BIAS) * DS);            // l = 4i, 4i+2
-                o[rr][2 * i + 1] = h2_bits((bits_h2(((v[rr] >> 8) & RB_M8) | RB_E) + BIAS) * DS);     // l = 4i+1, 4i+3
+                o[q][2 * i]     = h2_bits((bits_h2((v[q] & RB_M8) | RB_E) + BIAS) * DS);            // l = 4i, 4i+2
+                o[q][2 * i + 1] = h2_bits((bits_h2(((v[q] >> 8) & RB_M8) | RB_E) + BIAS) * DS);     // l = 4i+1, 4i+3
             }
         }
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            f[2 * rr]     = make_uint4(o[rr][0], o[rr][1], o[rr][2], o[rr][3]);
-            f[2 * rr + 1] = make_uint4(o[rr][4], o[rr][5], o[rr][6], o[rr][7]);
+        for (int q = 0; q < 2; ++q) {
+            f[2 * q]     = make_uint4(o[q][0], o[q][1], o[q][2], o[q][3]);
+            f[2 * q + 1] = make_uint4(o[q][4], o[q][5], o[q][6], o[q][7]);
         }
+    }
+    static __device__ __forceinline__ void unpack_h(const Raw & w, int h, uint4 (&f)[8]) {
+        uint4 lo[4], hi[4];
+        unpack_half<0>(w, h, lo);
+        unpack_half<1>(w, h, hi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[i] = lo[i]; f[4 + i] = hi[i]; }
     }
 };
 
@@ -344,14 +353,18 @@ __device__ __forceinline__ RegbFrag regb_unpack_q4k(const uint4 qs, const uint4 
     const f16x2 DS0 = { ds0, ds0 }, DS1 = { ds1, ds1 }, NO0 = { no0, no0 }, NO1 = { no1, no1 };
     const f16x2 BIAS = { (_Float16) -1024.0f, (_Float16) -1024.0f };
     const uint32_t w[4] = { qs.x, qs.y, qs.z, qs.w };
+    // low nibbles: (b & 0xf) | 0x6400 = 1024 + n; high nibbles in place: (b & 0xf0) | 0x5400 = 64 + n (ulp of 64.0 is 1/16):
+    // one shift per dword instead of three, same values
+    const f16x2 BIAS_H = { (_Float16) -64.0f, (_Float16) -64.0f };
     uint32_t lo[8], hi[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint32_t M = 0x000f000fu, E = 0x64006400u;
-        lo[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2((w[i] & M) | E) + BIAS, DS0, NO0));           // bytes 4i, 4i+2
-        lo[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((w[i] >> 8) & M) | E) + BIAS, DS0, NO0));    // bytes 4i+1, 4i+3
-        hi[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2(((w[i] >> 4) & M) | E) + BIAS, DS1, NO1));
-        hi[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((w[i] >> 12) & M) | E) + BIAS, DS1, NO1));
+        const uint32_t M = 0x000f000fu, E = 0x64006400u, MH = 0x00f000f0u, EH = 0x54005400u;
+        const uint32_t w8 = w[i] >> 8;
+        lo[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2((w[i] & M) | E) + BIAS, DS0, NO0));         // bytes 4i, 4i+2
+        lo[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2((w8 & M) | E) + BIAS, DS0, NO0));           // bytes 4i+1, 4i+3
+        hi[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2((w[i] & MH) | EH) + BIAS_H, DS1, NO1));
+        hi[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2((w8 & MH) | EH) + BIAS_H, DS1, NO1));
     }
     RegbFrag fr;
     fr.f0 = make_uint4(lo[0], lo[1], lo[2], lo[3]);
@@ -492,6 +505,173 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
         }
 }
 
+// ---- few tokens (N <= 64): 32 weight rows x 32*NA tokens per workgroup, K split over the workgroup's NWS waves ------------
+// With one or two token tiles the kernels above put < 1 workgroup on most CUs and every wave walks the whole of K behind a
+// two-K-step prefetch: HBM latency, not bandwidth, sets the time (31 us for a 9 MB matrix).  Here every (32 rows, K/NWS)
+// piece is its own wave.  The waves keep the lane -> bytes ownership of Regb<T> and read their A fragments (32 tokens x
+// 16 k, L2-resident) straight from the prepared activation matrix, which prep_act_kernel lays out fragment-major for this
+// kernel (one coalesced 1 KB load per fragment): no LDS tile and no barrier in the K loop.  What bounds the kernel is the
+// unpack VALU (the weights are unpacked for 32 or 64 tokens only) and, on matrices with fewer row groups than CUs, the
+// number of CUs pulling on HBM.  The NWS partial tiles meet in LDS; every thread sums its share of the outputs in wave
+// order (deterministic) and stores it.
+#ifdef QMM_SKINNY_TRACE
+__device__ uint64_t * g_trace;
+#define QMM_TR(slot) do { if (lane == 0) g_trace[(blockIdx.x * NWS + wave) * 4 + slot] = wall_clock64(); } while (0)
+#else
+#define QMM_TR(slot)
+#endif
+template <int T, int NWS, int NA>
+__global__ void __launch_bounds__(NWS * 64) __attribute__((amdgpu_waves_per_eu(NA == 1 ? 4 : 2)))
+mfma_skinny_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64_t expert_bytes, const int M, const int K,
+                   const uint16_t * __restrict__ Xh, const int Kp, const float * __restrict__ scale,
+                   const int * __restrict__ seg_start, const int * __restrict__ seg_count, const int N,
+                   float * __restrict__ dst, const int64_t ldd, const int64_t * __restrict__ dst_off) {
+    using P = Regb<T>;
+    constexpr int BK = P::BK, NFRAG = P::NFRAG, BN = 32 * NA, NT = NWS * 64;
+    constexpr int OUTS = NA * 1024 / NT;                       // outputs per thread in the epilogue
+    static_assert(NWS * NA * 4096 <= 65536, "partial tiles must fit the static LDS limit");
+
+    __shared__ float red[NWS * NA * 1024];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    QMM_TR(0);
+    const int seg0 = seg_start ? seg_start[blockIdx.z] : 0;
+    const int segn = seg_count ? seg_count[blockIdx.z] : N;
+    // token tiles of one row group are neighbours in launch order (the second tile finds the weights in L2)
+    const int lin  = blockIdx.x + gridDim.x * blockIdx.y;
+    const int tok0 = (lin % gridDim.y) * BN;
+    if (tok0 >= segn) return;
+    const int row0 = (lin / gridDim.y) * 32;
+    const int r = lane & 31, h = lane >> 5;
+    const uint8_t * wrow = W + (int64_t) blockIdx.z * expert_bytes + (int64_t) min(row0 + r, M - 1) * row_bytes;
+    const int nk = Kp / BK;
+    int per = (nk + NWS - 1) / NWS;                            // K-steps per wave
+    if (T == T_Q4_K) per = (per + 3) & ~3;                     // whole Q4_K blocks: compile-time sub-block index
+    const int kb = wave * per, ke = min(kb + per, nk);
+
+    // a K-step is SUB substeps of four 16-deep MFMA k-steps (Q6_K: 2, the others 1); A fragments are handled per substep
+    constexpr int SUB = NFRAG / 4;
+    struct XFr { uint4 a[NA * 4]; };
+    struct Frags { uint4 f[4]; };
+    // fragment-major operand (frag_major_chunk): the lane's chunk of k-step kk of K-step ks is chunk (ks*NFRAG + kk)*64 of its
+    // token tile, i.e. substep s = ks*SUB + sub holds chunks (4s + q)*64, q = 0..3
+    const uint4 * xrow[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int t = seg0 + min(tok0 + 32 * i + r, segn - 1);
+        xrow[i] = reinterpret_cast<const uint4 *>(Xh) + (int64_t) (t >> 5) * nk * (NFRAG * 64) + h * 32 + (t & 31);
+    }
+    auto load_x = [&](int s) {
+        XFr x;
+        const int s2 = min(s, nk * SUB - 1);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x.a[i * 4 + q] = xrow[i][(s2 * 4 + q) * 64];
+        return x;
+    };
+
+    f32x16 acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+    auto mfmas = [&](const Frags fr, const XFr x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f16x8 bb = *reinterpret_cast<const f16x8 *>(&fr.f[q]);
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&x.a[i * 4 + q]), bb, acc[i], 0, 0, 0);
+        }
+    };
+
+    // Register rings, statically indexed (the chunk loops are unrolled): weight bytes D K-steps ahead (HBM latency), A
+    // fragments one substep ahead (L2 latency).  vmcnt retires in order, so each step issues its fragment loads BEFORE its
+    // weight load: the wait for a substep's fragments (issued one substep ago) then never waits for the younger weight
+    // loads.  Every wave runs the same number of steps; steps past the wave's range get zero scales.
+    XFr xq[2];
+    xq[0] = load_x(kb * SUB);
+    if constexpr (T == T_Q4_K) {
+        const int nblk = K / 256, b0 = kb >> 2, be = ke >> 2;
+        auto ld_q = [&](int b, int j) { return ldg<uint4>(wrow + (size_t) min(b, nblk - 1) * 144 + 16 + 32 * j + 16 * h); };
+        auto ld_h = [&](int b) { uint4 v = ldg<uint4>(wrow + (size_t) min(b, nblk - 1) * 144); if (b >= be) v.x = 0; return v; };
+        uint4 q[4], hdr = ld_h(b0), hdr_n = hdr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = ld_q(b0, j);
+        for (int b = b0; b < b0 + (per >> 2); ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xq[(j + 1) & 1] = load_x(4 * b + j + 1);
+                const uint4 cur = q[j];
+                q[j] = ld_q(b + 1, j);
+                if (j == 0) hdr_n = ld_h(b + 1);
+                const RegbFrag rf = regb_unpack_q4k(cur, hdr, j);
+                Frags fr;
+                fr.f[0] = rf.f0; fr.f[1] = rf.f1; fr.f[2] = rf.f2; fr.f[3] = rf.f3;
+                mfmas(fr, xq[j & 1]);
+            }
+            hdr = hdr_n;
+        }
+    } else {
+        constexpr int D = T == T_Q6_K ? 2 : 4;
+        typename P::Raw wq[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) wq[d] = P::load(wrow, kb + d < ke ? kb + d : nk, h, K);
+        const int chunks = (per + D - 1) / D;
+        for (int c = 0; c < chunks; ++c) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int ks = kb + c * D + d;
+                const typename P::Raw cur = wq[d];
+#pragma unroll
+                for (int sub = 0; sub < SUB; ++sub) {
+                    const int par = (d * SUB + sub) & 1;
+                    xq[par ^ 1] = load_x(ks * SUB + sub + 1);
+                    if (sub == 0) wq[d] = P::load(wrow, ks + D < ke ? ks + D : nk, h, K);
+                    Frags fr;
+                    if constexpr (T == T_Q6_K) { if (sub == 0) P::template unpack_half<0>(cur, h, fr.f); else P::template unpack_half<1>(cur, h, fr.f); }
+                    else                       P::unpack(cur, ks, fr.f);
+                    mfmas(fr, xq[par]);
+                }
+            }
+        }
+    }
+
+    QMM_TR(1);
+    // the NWS partial tiles -> LDS; thread `tid` owns outputs tid, tid + NT, ...: output o = (tile i, acc element e, lane l)
+    {
+        float * o = red + wave * (NA * 1024) + lane;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[(i * 16 + e) * 64] = acc[i][e];
+    }
+    float   sc[OUTS];
+    int64_t off[OUTS];
+    bool    live[OUTS];
+#pragma unroll
+    for (int j = 0; j < OUTS; ++j) {                          // issued before the barrier: their latency hides behind it
+        const int o = tid + j * NT, l = o & 63, e = (o >> 6) & 15, i = o >> 10;
+        const int t = tok0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+        live[j] = t < segn && row0 + (l & 31) < M;
+        const int tc = seg0 + min(t, segn - 1);
+        sc[j]  = scale[tc];
+        off[j] = (dst_off ? dst_off[tc] : (int64_t) (tc - seg0) * ldd) + row0 + (l & 31);
+    }
+    __syncthreads();
+    QMM_TR(2);
+#pragma unroll
+    for (int j = 0; j < OUTS; ++j) {
+        const int o = tid + j * NT;
+        float sum = red[o];
+#pragma unroll
+        for (int w = 1; w < NWS; ++w) sum += red[w * (NA * 1024) + o];
+        if (live[j]) dst[off[j]] = sum * sc[j];
+    }
+    QMM_TR(3);
+}
+
 inline bool mfma_regb_supports(const qmm_ctx * c, int type) {
     return c->prec == QMM_PREC_F16_Q8 && (type == T_Q4_K || type == T_Q5_K || type == T_Q6_K || type == T_Q4_0 || type == T_Q8_0);
 }
@@ -512,11 +692,18 @@ inline int launch_mfma_regb_t(qmm_ctx * c, hipStream_t st, const void * W, int64
         hipLaunchKernelGGL(kern, dim3((M + ROWS - 1) / ROWS, TY, n_expert), dim3(NWv * 64), lds, st, (const uint8_t *) W, rb, eb,      \
                            M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off);                                  \
     } while (0)
-    if (wg_256 * 10 >= (int64_t) c->cus * 8) QMM_REGB(8, 128, 256, n_tiles_y);
+#define QMM_SKINNY(NWSv, NAv)                                                                                                          \
+    hipLaunchKernelGGL((mfma_skinny_kernel<T, NWSv, NAv>), dim3((M + 31) / 32, (N + 32 * NAv - 1) / (32 * NAv), n_expert),             \
+                       dim3(NWSv * 64), 0, st, (const uint8_t *) W, rb, eb, M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N,     \
+                       dst, ldd, dst_off)
+    if (op.frag_major && N <= 32) QMM_SKINNY(8, 1);           // (16 waves per group measured no better, Q6_K worse)
+    else if (op.frag_major)       QMM_SKINNY(8, 2);
+    else if (wg_256 * 10 >= (int64_t) c->cus * 8) QMM_REGB(8, 128, 256, n_tiles_y);
     else if (wg_128 >= c->cus)              QMM_REGB(4, 128, 128, n_tiles_y);
     else if (2 * wg_128 >= c->cus / 2)       QMM_REGB(4, 64, 128, 2 * n_tiles_y);
     else                                     QMM_REGB(4, 32, 128, 4 * n_tiles_y);
 #undef QMM_REGB
+#undef QMM_SKINNY
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }

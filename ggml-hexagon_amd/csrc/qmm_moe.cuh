@@ -164,10 +164,11 @@ inline int moe_mul_mat_id(qmm_ctx * c, hipStream_t st, int type, const void * as
                        (int) n_expert, (int) ne11, b_s1, b_s2, d_s1, d_s2, seg_start, seg_count, n_live, gather, dst_off, c->flag);
     HIP_TRY(hipGetLastError());
     const bool q8_0 = (type == T_Q4_0 || type == T_Q8_0);
-    rc = q8_0 ? launch_prep<T_Q8_0>(c, st, type, b, 0, gather, n_live, (int) P, (int) P, (int) K, Kp, xh, scale)
-              : launch_prep<T_Q8_K>(c, st, type, b, 0, gather, n_live, (int) P, (int) P, (int) K, Kp, xh, scale);
+    const int frag = mfma_use_skinny(c, type, P, M, n_expert);
+    rc = q8_0 ? launch_prep<T_Q8_0>(c, st, type, b, 0, gather, n_live, (int) P, (int) P, (int) K, Kp, frag, xh, scale)
+              : launch_prep<T_Q8_K>(c, st, type, b, 0, gather, n_live, (int) P, (int) P, (int) K, Kp, frag, xh, scale);
     if (rc) return rc;
-    MfmaOperand op = { xh, scale, Kp };
+    MfmaOperand op = { xh, scale, Kp, frag };
     return launch_mfma_any(c, st, type, as, rb, eb, (int) n_expert, (int) M, (int) K, op, seg_start, seg_count, (int) P,
                            (int) ((P + 127) / 128), dst, 0, dst_off);
 }

@@ -190,7 +190,7 @@ def test_group_launch_matches_single(qmm, maybe_ref):
 # ----------------------------------------------------------------------------- MFMA path (N > 8)
 
 @pytest.mark.parametrize("t", ALL, ids=IDS)
-@pytest.mark.parametrize("n", [9, 32, 129, 512])
+@pytest.mark.parametrize("n", [9, 32, 33, 64, 129, 512])
 def test_mfma_f16q8_vs_oracle(qmm, oracle, maybe_ref, t, n):
     k, m = 2048, 200
     w = weights(maybe_ref, t, m, k, seed=20 + t)
