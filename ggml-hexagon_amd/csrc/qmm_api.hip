@@ -121,7 +121,9 @@ qmm_ctx * qmm_create(int device) {
         delete c;
         return nullptr;
     }
-    const char * e = getenv("GGML_MI355X_ACT_MODE");
+    const char * e = getenv("GGML_MI355X_SPLITK");
+    if (e) c->splitk = atoi(e);
+    e = getenv("GGML_MI355X_ACT_MODE");
     if (e) c->act_mode = atoi(e) ? QMM_ACT_X86 : QMM_ACT_REF;
     e = getenv("GGML_MI355X_MV_BPC");
     if (e && atoi(e) >= 1 && atoi(e) <= 8) c->mv_bpc = atoi(e);

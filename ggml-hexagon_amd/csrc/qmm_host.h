@@ -26,6 +26,7 @@ struct qmm_ctx {
     void *      ws = nullptr;
     size_t      ws_bytes = 0;
     int *       flag = nullptr;      // device word set by kernels that meet an expert id out of range
+    int         splitk = 1;          // split K over workgroups when a MUL_MAT has too few tiles (GGML_MI355X_SPLITK=0: off)
     char        name[128] = {0};
 
     // `st` is used verbatim: NULL is HIP's default stream (what torch's default stream is), not ours

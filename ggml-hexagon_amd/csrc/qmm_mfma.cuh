@@ -449,6 +449,8 @@ struct MfmaOperand {            // a prepared activation matrix in the workspace
     const float *    scale;
     int              Kp;
     int              frag_major;   // layout of xh: 0 = rows of Kp, 1 = fragment-major (frag_major_chunk)
+    int              ksplit = 1;   // > 1: K is split over this many workgroups per tile (256 rows x 128 tokens), partial
+    float *          part = nullptr;   //  tiles go to part[range][token][row] (mfma_splitk, splitk_reduce_kernel)
 };
 
 template <int ACT>
@@ -522,6 +524,22 @@ inline int launch_mfma_any(qmm_ctx * c, hipStream_t st, int type, const void * W
     }
 }
 
+// Split-K factor for the tiled register-B kernel on a plain MUL_MAT.  One 256-row x 128-token tile over K = 4096 is 27 us
+// of MFMA time on its CU however few tiles there are, and 4096 x 4096 at 512 tokens is only 64 tiles; K is therefore cut
+// into ranges (one workgroup each, partial tiles to the workspace, splitk_reduce_kernel adds them) until the launch has
+// about as many workgroups as the chip has CUs.  Each extra range costs one more N x M f32 slab to write and read.
+inline int mfma_splitk(const qmm_ctx * c, int type, int64_t M, int64_t K, int64_t N) {
+    if (!mfma_regb_supports(c, type) || !c->splitk || mfma_use_skinny(c, type, N, M)) return 1;
+    const int64_t tiles = (M + 255) / 256 * ((N + 127) / 128);
+    if (tiles * 10 >= (int64_t) c->cus * 8) return 1;
+    int64_t s = c->cus / tiles;
+    if (s > 8) s = 8;
+    if (c->splitk > 1 && s > c->splitk) s = c->splitk;       // (GGML_MI355X_SPLITK=n caps the factor; for experiments)
+    if (s > K / 512) s = K / 512;
+    return s < 2 ? 1 : (int) s;
+}
+inline size_t mfma_splitk_bytes(int ksplit, int64_t M, int64_t N) { return ksplit > 1 ? (size_t) ksplit * N * M * sizeof(float) : 0; }
+
 // what the prepared operand depends on besides src1 itself: Q8_0 vs Q8_K emulation and the k-order of the unpack
 inline int mfma_prep_key(const qmm_ctx * c, int type, int64_t N, int64_t M) {
     if (c->prec != QMM_PREC_F16_Q8) return 0;
@@ -534,7 +552,9 @@ inline int mfma_mul_mat(qmm_ctx * c, hipStream_t st, int type, const void * W, i
                         const float * x, int64_t N, int64_t ldx, float * dst, int64_t ldd, bool reuse_prep) {
     const int Kp = mfma_kpad(K), Np = mfma_npad(N);
     const size_t xh_bytes = (size_t) Np * Kp * 2;
-    const size_t need = xh_bytes + (size_t) Np * 4 + 256;
+    const int ksplit = mfma_splitk(c, type, M, K, N);
+    const size_t sc_bytes = ((size_t) Np * 4 + 255) & ~(size_t) 255;
+    const size_t need = xh_bytes + sc_bytes + mfma_splitk_bytes(ksplit, M, N) + 256;
     int rc = ensure_ws(c, need);
     if (rc) return rc;
     uint16_t * xh = (uint16_t *) c->ws;
@@ -547,6 +567,8 @@ inline int mfma_mul_mat(qmm_ctx * c, hipStream_t st, int type, const void * W, i
         if (rc) return rc;
     }
     MfmaOperand op = { xh, scale, Kp, frag };
+    op.ksplit = ksplit;
+    op.part = reinterpret_cast<float *>((uint8_t *) c->ws + xh_bytes + sc_bytes);
     return launch_mfma_any(c, st, type, W, rb, 0, 1, (int) M, (int) K, op, nullptr, nullptr, (int) N, Np / 128, dst, ldd, nullptr);
 }
 

@@ -226,12 +226,43 @@ template <> struct Regb<T_Q6_K> {
     }
 };
 
+// ---- split-K across workgroups (plain MUL_MAT on matrices with too few tiles to fill the chip) ----------------------------
+// blockIdx.z = which K range.  A workgroup of range s stores its unscaled f32 tile to part[s][token][row] (plain coalesced
+// stores, no flags); splitk_reduce_kernel then adds the ranges in order (deterministic), applies the per-token scale and
+// writes dst.  (An in-kernel combine by the last workgroup to arrive at a tile counter was measured first: with 128 KB
+// tiles its serial read of the other ranges cost more than the split gained; the extra launch is ~2 us and runs chip-wide.)
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float * __restrict__ part, const int ksplit, const int N, const int M, const float * __restrict__ scale,
+                     float * __restrict__ dst, const int64_t ldd, const int vec) {
+    const int64_t range = (int64_t) N * M;
+    if (vec) {                                                 // M % 4 == 0, ldd % 4 == 0, dst 16-byte aligned
+        const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+        if (i >= range) return;
+        float4 a = *reinterpret_cast<const float4 *>(part + i);
+        for (int s = 1; s < ksplit; ++s) {
+            const float4 b = *reinterpret_cast<const float4 *>(part + s * range + i);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const int t = (int) (i / M), m = (int) (i - (int64_t) t * M);
+        const float sc = scale[t];
+        *reinterpret_cast<float4 *>(dst + t * ldd + m) = make_float4(a.x * sc, a.y * sc, a.z * sc, a.w * sc);
+    } else {
+        const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+        if (i >= range) return;
+        float a = part[i];
+        for (int s = 1; s < ksplit; ++s) a += part[s * range + i];
+        const int t = (int) (i / M), m = (int) (i - (int64_t) t * M);
+        dst[t * ldd + m] = a * scale[t];
+    }
+}
+
 template <int T, int NW, int BN>   // weight type, waves per workgroup, tokens per tile: tile = 32*NW weight rows x BN tokens
 __global__ void __launch_bounds__(NW * 64)
 mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64_t expert_bytes, const int M, const int K,
                  const uint16_t * __restrict__ Xh, const int Kp, const float * __restrict__ scale,
                  const int * __restrict__ seg_start, const int * __restrict__ seg_count, const int N,
-                 float * __restrict__ dst, const int64_t ldd, const int64_t * __restrict__ dst_off) {
+                 float * __restrict__ dst, const int64_t ldd, const int64_t * __restrict__ dst_off,
+                 const int ksplit, float * __restrict__ part) {
     using P = Regb<T>;
     constexpr int BK = P::BK, NFRAG = P::NFRAG, ROWB = BK * 2, SLOTS = BK / 8, NA = BN / 32;
     constexpr int NT = NW * 64;
@@ -242,14 +273,17 @@ mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // 2 stages
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int seg0 = seg_start ? seg_start[blockIdx.z] : 0;
-    const int segn = seg_count ? seg_count[blockIdx.z] : N;
+    const int expert = ksplit > 1 ? 0 : blockIdx.z, split = ksplit > 1 ? blockIdx.z : 0;
+    const int seg0 = seg_start ? seg_start[expert] : 0;
+    const int segn = seg_count ? seg_count[expert] : N;
     const int tok0 = blockIdx.y * BN;
-    if (tok0 >= segn) return;
+    if (tok0 >= segn) return;                                 // (never with ksplit > 1: plain MUL_MAT has no empty tiles)
     const int row0 = blockIdx.x * (32 * NW) + wave * 32;
     const int r = lane & 31, h = lane >> 5;
-    const uint8_t * wrow = W + (int64_t) blockIdx.z * expert_bytes + (int64_t) min(row0 + r, M - 1) * row_bytes;
+    const uint8_t * wrow = W + (int64_t) expert * expert_bytes + (int64_t) min(row0 + r, M - 1) * row_bytes;
     const int nk = Kp / BK;                                   // even: Kp is a multiple of 128 (256 for the K-quants)
+    const int per = ((nk + ksplit - 1) / ksplit + 1) & ~1;    // this workgroup's K-steps: [ks0, ks1), an even count
+    const int ks0 = split * per, ks1 = min(ks0 + per, nk);
 
     const uint8_t * xthr = reinterpret_cast<const uint8_t *>(Xh + (int64_t) (seg0 + tok0) * Kp) +
                            (size_t) (tid / SLOTS) * Kp * 2 + (tid % SLOTS) * 16;
@@ -299,13 +333,13 @@ mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const 
 
     // software pipeline: weight bytes two K-steps ahead in registers (even/odd slots), activation chunks two K-steps
     // ahead in registers and one K-step ahead in LDS
-    typename P::Raw w_e = P::load(wrow, 0, h, K), w_o = P::load(wrow, 1, h, K);
-    XRegs x_e = load_x(0), x_o = load_x(1);
+    typename P::Raw w_e = P::load(wrow, ks0, h, K), w_o = P::load(wrow, ks0 + 1, h, K);
+    XRegs x_e = load_x(ks0), x_o = load_x(ks0 + 1);
     store_x(x_e, lds);
-    x_e = load_x(2);
+    x_e = load_x(ks0 + 2);
     __syncthreads();
 
-    for (int ks = 0; ks < nk; ks += 2) {
+    for (int ks = ks0; ks < ks1; ks += 2) {
         Frags fr = unpack(w_e, ks);
         w_e = P::load(wrow, ks + 2, h, K);
         store_x(x_o, lds + STAGE);  x_o = load_x(ks + 3);
@@ -318,14 +352,16 @@ mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const 
         __syncthreads();
     }
 
-    // epilogue: per-token scales / dst row offsets staged through LDS (all reads of the tiles are behind the last barrier)
+    // epilogue: per-token scales / dst row offsets staged through LDS (all reads of the tiles are behind the last barrier).
+    // A split-K range stores its unscaled tile to part[split][token][row] instead (splitk_reduce_kernel finishes the job).
     float *   sc_lds  = reinterpret_cast<float *>(lds);
     int64_t * off_lds = reinterpret_cast<int64_t *>(lds + 1024);
+    float *   out     = ksplit > 1 ? part + (int64_t) split * N * M : dst;
     if (tid < BN) {
         const int t = tok0 + tid;
         const bool live = t < segn;
-        sc_lds[tid]  = live ? scale[seg0 + t] : 0.0f;
-        off_lds[tid] = live ? (dst_off ? dst_off[seg0 + t] : (int64_t) t * ldd) : 0;
+        sc_lds[tid]  = live ? (ksplit > 1 ? 1.0f : scale[seg0 + t]) : 0.0f;
+        off_lds[tid] = live ? (ksplit > 1 ? (int64_t) t * M : dst_off ? dst_off[seg0 + t] : (int64_t) t * ldd) : 0;
     }
     __syncthreads();
     const int m = row0 + r;
@@ -334,7 +370,7 @@ mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int tl = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (tok0 + tl < segn && m < M) dst[off_lds[tl] + m] = acc[i][e] * sc_lds[tl];
+            if (tok0 + tl < segn && m < M) out[off_lds[tl] + m] = acc[i][e] * sc_lds[tl];
         }
 }
 
@@ -379,7 +415,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1,
 mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64_t expert_bytes, const int M, const int K,
                      const uint16_t * __restrict__ Xh, const int Kp, const float * __restrict__ scale,
                      const int * __restrict__ seg_start, const int * __restrict__ seg_count, const int N,
-                     float * __restrict__ dst, const int64_t ldd, const int64_t * __restrict__ dst_off) {
+                     float * __restrict__ dst, const int64_t ldd, const int64_t * __restrict__ dst_off,
+                     const int ksplit, float * __restrict__ part) {
     constexpr int BK = 64, ROWB = BK * 2, SLOTS = 8, NA = BN / 32;
     constexpr int NT = NW * 64;
     constexpr int X_CHUNKS = BN * SLOTS / NT;                 // 16-byte chunks of the activation tile per thread per K-step
@@ -388,15 +425,18 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int seg0 = seg_start ? seg_start[blockIdx.z] : 0;
-    const int segn = seg_count ? seg_count[blockIdx.z] : N;
+    const int expert = ksplit > 1 ? 0 : blockIdx.z, split = ksplit > 1 ? blockIdx.z : 0;
+    const int seg0 = seg_start ? seg_start[expert] : 0;
+    const int segn = seg_count ? seg_count[expert] : N;
     const int tok0 = blockIdx.y * BN;
-    if (tok0 >= segn) return;
+    if (tok0 >= segn) return;                                 // (never with ksplit > 1: plain MUL_MAT has no empty tiles)
     const int row0 = blockIdx.x * (32 * NW) + wave * 32;
     const int r = lane & 31, h = lane >> 5;
-    const uint8_t * wrow = W + (int64_t) blockIdx.z * expert_bytes + (int64_t) min(row0 + r, M - 1) * row_bytes;
+    const uint8_t * wrow = W + (int64_t) expert * expert_bytes + (int64_t) min(row0 + r, M - 1) * row_bytes;
     const int nk = Kp / BK;                                   // K % 256 == 0 for Q4_K: nk is a multiple of 4
     const int nblk = K / 256;
+    const int bper = (nblk + ksplit - 1) / ksplit;            // this workgroup's Q4_K blocks: [kb0, kb1)
+    const int kb0 = split * bper, kb1 = min(kb0 + bper, nblk);
 
     const uint8_t * xthr = reinterpret_cast<const uint8_t *>(Xh + (int64_t) (seg0 + tok0) * Kp) +
                            (size_t) (tid / SLOTS) * Kp * 2 + (tid % SLOTS) * 16;
@@ -447,14 +487,14 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
 
     // software pipeline: weight bytes two K-steps ahead in registers (even/odd slots), header one block ahead,
     // activation chunks two K-steps ahead in registers and one K-step ahead in LDS
-    uint4 q_e = load_qs(0), q_o = load_qs(1);
-    uint4 hdr = load_hdr(0), hdr_n = load_hdr(1);
-    XRegs x_e = load_x(0), x_o = load_x(1);
+    uint4 q_e = load_qs(4 * kb0), q_o = load_qs(4 * kb0 + 1);
+    uint4 hdr = load_hdr(kb0), hdr_n = load_hdr(kb0 + 1);
+    XRegs x_e = load_x(4 * kb0), x_o = load_x(4 * kb0 + 1);
     store_x(x_e, lds);
-    x_e = load_x(2);
+    x_e = load_x(4 * kb0 + 2);
     __syncthreads();
 
-    for (int kb = 0; kb < nblk; ++kb) {                       // one Q4_K block (256 k) = four K-steps, j = 0..3
+    for (int kb = kb0; kb < kb1; ++kb) {                      // one Q4_K block (256 k) = four K-steps, j = 0..3
         const int ks = 4 * kb;
         RegbFrag fr;
         // j = 0 (even): stage buffer 0
@@ -485,14 +525,16 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
         __syncthreads();
     }
 
-    // epilogue: per-token scales / dst row offsets staged through LDS (all reads of the tiles are behind the last barrier)
+    // epilogue: per-token scales / dst row offsets staged through LDS (all reads of the tiles are behind the last barrier).
+    // A split-K range stores its unscaled tile to part[split][token][row] instead (splitk_reduce_kernel finishes the job).
     float *   sc_lds  = reinterpret_cast<float *>(lds);
     int64_t * off_lds = reinterpret_cast<int64_t *>(lds + 1024);
+    float *   out     = ksplit > 1 ? part + (int64_t) split * N * M : dst;
     if (tid < BN) {
         const int t = tok0 + tid;
         const bool live = t < segn;
-        sc_lds[tid]  = live ? scale[seg0 + t] : 0.0f;
-        off_lds[tid] = live ? (dst_off ? dst_off[seg0 + t] : (int64_t) t * ldd) : 0;
+        sc_lds[tid]  = live ? (ksplit > 1 ? 1.0f : scale[seg0 + t]) : 0.0f;
+        off_lds[tid] = live ? (ksplit > 1 ? (int64_t) t * M : dst_off ? dst_off[seg0 + t] : (int64_t) t * ldd) : 0;
     }
     __syncthreads();
     const int m = row0 + r;
@@ -501,7 +543,7 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int tl = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (tok0 + tl < segn && m < M) dst[off_lds[tl] + m] = acc[i][e] * sc_lds[tl];
+            if (tok0 + tl < segn && m < M) out[off_lds[tl] + m] = acc[i][e] * sc_lds[tl];
         }
 }
 
@@ -683,14 +725,15 @@ inline int launch_mfma_regb_t(qmm_ctx * c, hipStream_t st, const void * W, int64
     // tile choice = chip fill: 256 rows x 128 tokens (8 waves, two per SIMD) when that gives (almost) every CU a workgroup,
     // else 128 x 128, else 128 x 64 / 128 x 32 (the weight unpack is then repeated 2x / 4x, on CUs that would otherwise idle).
     // n_tiles_y counts 128-token tiles of the (worst-case) token range.
+    const int ksplit = n_expert == 1 ? op.ksplit : 1;
     const int64_t wg_256 = (int64_t) ((M + 255) / 256) * n_tiles_y * n_expert;
     const int64_t wg_128 = (int64_t) ((M + 127) / 128) * n_tiles_y * n_expert;
 #define QMM_REGB(NWv, BNv, ROWS, TY)                                                                                                   \
     do {                                                                                                                               \
         auto kern = T == T_Q4_K ? mfma_regb_q4k_kernel<NWv, BNv> : mfma_regb_kernel<T, NWv, BNv>;                                      \
         const size_t lds = (size_t) 2 * BNv * Regb<T>::BK * 2 < 2048 ? 2048 : (size_t) 2 * BNv * Regb<T>::BK * 2;                     \
-        hipLaunchKernelGGL(kern, dim3((M + ROWS - 1) / ROWS, TY, n_expert), dim3(NWv * 64), lds, st, (const uint8_t *) W, rb, eb,      \
-                           M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off);                                  \
+        hipLaunchKernelGGL(kern, dim3((M + ROWS - 1) / ROWS, TY, n_expert * ksplit), dim3(NWv * 64), lds, st, (const uint8_t *) W,     \
+                           rb, eb, M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off, ksplit, op.part);         \
     } while (0)
 #define QMM_SKINNY(NWSv, NAv)                                                                                                          \
     hipLaunchKernelGGL((mfma_skinny_kernel<T, NWSv, NAv>), dim3((M + 31) / 32, (N + 32 * NAv - 1) / (32 * NAv), n_expert),             \
@@ -698,12 +741,18 @@ inline int launch_mfma_regb_t(qmm_ctx * c, hipStream_t st, const void * W, int64
                        dst, ldd, dst_off)
     if (op.frag_major && N <= 32) QMM_SKINNY(8, 1);           // (16 waves per group measured no better, Q6_K worse)
     else if (op.frag_major)       QMM_SKINNY(8, 2);
-    else if (wg_256 * 10 >= (int64_t) c->cus * 8) QMM_REGB(8, 128, 256, n_tiles_y);
+    else if (ksplit > 1 || wg_256 * 10 >= (int64_t) c->cus * 8) QMM_REGB(8, 128, 256, n_tiles_y);
     else if (wg_128 >= c->cus)              QMM_REGB(4, 128, 128, n_tiles_y);
     else if (2 * wg_128 >= c->cus / 2)       QMM_REGB(4, 64, 128, 2 * n_tiles_y);
     else                                     QMM_REGB(4, 32, 128, 4 * n_tiles_y);
 #undef QMM_REGB
 #undef QMM_SKINNY
+    if (ksplit > 1 && !op.frag_major) {
+        const int vec = M % 4 == 0 && ldd % 4 == 0 && ((uintptr_t) dst & 15) == 0;
+        const int64_t items = ((int64_t) N * M + (vec ? 3 : 0)) / (vec ? 4 : 1);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned) ((items + 255) / 256)), dim3(256), 0, st, op.part, ksplit, N, M,
+                           op.scale, dst, ldd, vec);
+    }
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }
