@@ -22,6 +22,8 @@
 // the next K-step's unpack under the MFMAs with sched_group_barrier.
 #pragma once
 
+#include <type_traits>
+
 #include "qmm_mfma.cuh"
 #include "qmm_mvunit.cuh"
 
@@ -466,64 +468,96 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
             *reinterpret_cast<uint4 *>(stage + tile_off<BK>(c / SLOTS, c % SLOTS)) = x.c[i];
         }
     };
-    // 4 fragment reads + 4 MFMAs per 16-deep k-step, on this lane's B fragment.  (Measured alternatives that did NOT help:
-    // pinning 8 reads ahead of the MFMAs with sched_group_barrier; interleaving the next K-step's unpack VALU under the
-    // MFMAs; both leave the K-step time unchanged or worse.)
-    auto mfma4 = [&](const uint4 b, const uint8_t * stage, int slot) {
-        uint4 a[NA];
+    struct AFr { uint4 a[NA]; };
+    auto read_a = [&](const uint8_t * stage, int slot) {
+        AFr f;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) a[i] = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(32 * i + r, slot));
+        for (int i = 0; i < NA; ++i) f.a[i] = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(32 * i + r, slot));
+        return f;
+    };
+    auto mfma_a = [&](const uint4 b, const AFr f) {
         const f16x8 bb = *reinterpret_cast<const f16x8 *>(&b);
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a[i]), bb, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&f.a[i]), bb, acc[i], 0, 0, 0);
     };
+    // the A fragments of k-step kk+1 are read before the MFMAs of k-step kk are issued (two register sets), and the order is
+    // pinned: left to itself the scheduler issues the next reads only behind the last MFMA of a group, and the matrix core
+    // then idles for an LDS latency per group
     auto compute = [&](const RegbFrag fr, const uint8_t * stage) {
-        mfma4(fr.f0, stage, 0 + h);
-        mfma4(fr.f1, stage, 2 + h);
-        mfma4(fr.f2, stage, 4 + h);
-        mfma4(fr.f3, stage, 6 + h);
+        const AFr a0 = read_a(stage, 0 + h);
+        const AFr a1 = read_a(stage, 2 + h);
+        mfma_a(fr.f0, a0);
+        const AFr a2 = read_a(stage, 4 + h);
+        mfma_a(fr.f1, a1);
+        const AFr a3 = read_a(stage, 6 + h);
+        mfma_a(fr.f2, a2);
+        mfma_a(fr.f3, a3);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NA, 0);   // 2 x NA ds reads
+        __builtin_amdgcn_sched_group_barrier(0x008, NA, 0);       // NA MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NA, 0);
     };
 
-    // software pipeline: weight bytes two K-steps ahead in registers (even/odd slots), header one block ahead,
-    // activation chunks two K-steps ahead in registers and one K-step ahead in LDS
+    // software pipeline: weight bytes two K-steps ahead in registers (even/odd slots), header one block ahead, activation
+    // chunks two K-steps ahead in registers and one K-step ahead in LDS, B fragments one K-step ahead: between two barriers a
+    // wave unpacks the NEXT K-step's fragments (VALU) and runs this K-step's MFMAs.  The two waves that share a SIMD do these
+    // in opposite order (waves < NW/2 unpack first, the others multiply first), so that behind every barrier one of them feeds
+    // the VALU while the other feeds the matrix core, instead of both unpacking and then both multiplying.
     uint4 q_e = load_qs(4 * kb0), q_o = load_qs(4 * kb0 + 1);
     uint4 hdr = load_hdr(kb0), hdr_n = load_hdr(kb0 + 1);
     XRegs x_e = load_x(4 * kb0), x_o = load_x(4 * kb0 + 1);
     store_x(x_e, lds);
     x_e = load_x(4 * kb0 + 2);
+    RegbFrag fr = regb_unpack_q4k(q_e, hdr, 0);
+    q_e = load_qs(4 * kb0 + 2);
     __syncthreads();
 
-    for (int kb = kb0; kb < kb1; ++kb) {                      // one Q4_K block (256 k) = four K-steps, j = 0..3
-        const int ks = 4 * kb;
-        RegbFrag fr;
-        // j = 0 (even): stage buffer 0
-        fr = regb_unpack_q4k(q_e, hdr, 0);
-        q_e = load_qs(ks + 2);
-        store_x(x_o, lds + STAGE);  x_o = load_x(ks + 3);
-        compute(fr, lds);
-        __syncthreads();
-        // j = 1 (odd): stage buffer 1
-        fr = regb_unpack_q4k(q_o, hdr, 1);
-        q_o = load_qs(ks + 3);
-        store_x(x_e, lds);          x_e = load_x(ks + 4);
-        compute(fr, lds + STAGE);
-        __syncthreads();
-        // j = 2
-        fr = regb_unpack_q4k(q_e, hdr, 2);
-        q_e = load_qs(ks + 4);
-        store_x(x_o, lds + STAGE);  x_o = load_x(ks + 5);
-        compute(fr, lds);
-        __syncthreads();
-        // j = 3
-        fr = regb_unpack_q4k(q_o, hdr, 3);
-        q_o = load_qs(ks + 5);
-        hdr = hdr_n;
-        hdr_n = load_hdr(kb + 2);
-        store_x(x_e, lds);          x_e = load_x(ks + 6);
-        compute(fr, lds + STAGE);
-        __syncthreads();
-    }
+    auto run = [&](auto unpack_first) {
+        constexpr bool UF = decltype(unpack_first)::value;
+        for (int kb = kb0; kb < kb1; ++kb) {                  // one Q4_K block (256 k) = four K-steps, j = 0..3
+            const int ks = 4 * kb;
+            RegbFrag frn;
+            // j = 0: multiply step ks (stage 0), unpack step ks+1 (odd slot)
+            if (UF) frn = regb_unpack_q4k(q_o, hdr, 1);
+            store_x(x_o, lds + STAGE);  x_o = load_x(ks + 3);
+            compute(fr, lds);
+            if (!UF) frn = regb_unpack_q4k(q_o, hdr, 1);
+            q_o = load_qs(ks + 3);
+            __syncthreads();
+            fr = frn;
+            // j = 1
+            if (UF) frn = regb_unpack_q4k(q_e, hdr, 2);
+            store_x(x_e, lds);          x_e = load_x(ks + 4);
+            compute(fr, lds + STAGE);
+            if (!UF) frn = regb_unpack_q4k(q_e, hdr, 2);
+            q_e = load_qs(ks + 4);
+            __syncthreads();
+            fr = frn;
+            // j = 2
+            if (UF) frn = regb_unpack_q4k(q_o, hdr, 3);
+            store_x(x_o, lds + STAGE);  x_o = load_x(ks + 5);
+            compute(fr, lds);
+            if (!UF) frn = regb_unpack_q4k(q_o, hdr, 3);
+            q_o = load_qs(ks + 5);
+            __syncthreads();
+            fr = frn;
+            // j = 3: the next K-step is sub-block 0 of the next block
+            if (UF) frn = regb_unpack_q4k(q_e, hdr_n, 0);
+            store_x(x_e, lds);          x_e = load_x(ks + 6);
+            compute(fr, lds + STAGE);
+            if (!UF) frn = regb_unpack_q4k(q_e, hdr_n, 0);
+            q_e = load_qs(ks + 6);
+            hdr = hdr_n;
+            hdr_n = load_hdr(kb + 2);
+            __syncthreads();
+            fr = frn;
+        }
+    };
+    if (NW >= 8 && wave >= NW / 2) run(std::false_type{});
+    else                           run(std::true_type{});
 
     // epilogue: per-token scales / dst row offsets staged through LDS (all reads of the tiles are behind the last barrier).
     // A split-K range stores its unscaled tile to part[split][token][row] instead (splitk_reduce_kernel finishes the job).
