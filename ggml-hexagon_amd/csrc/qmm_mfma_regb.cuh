@@ -259,7 +259,7 @@ splitk_reduce_kernel(const float * __restrict__ part, const int ksplit, const in
 }
 
 template <int T, int NW, int BN>   // weight type, waves per workgroup, tokens per tile: tile = 32*NW weight rows x BN tokens
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const int64_t expert_bytes, const int M, const int K,
                  const uint16_t * __restrict__ Xh, const int Kp, const float * __restrict__ scale,
                  const int * __restrict__ seg_start, const int * __restrict__ seg_count, const int N,
@@ -314,44 +314,97 @@ mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const 
             *reinterpret_cast<uint4 *>(stage + tile_off<BK>(c / SLOTS, c % SLOTS)) = x.c[i];
         }
     };
+    struct AFr { uint4 a[NA]; };
+    auto read_a = [&](const uint8_t * stage, int slot) {
+        AFr f;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) f.a[i] = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(32 * i + r, slot));
+        return f;
+    };
+    auto mfma_a = [&](const uint4 b, const AFr f) {
+        const f16x8 bb = *reinterpret_cast<const f16x8 *>(&b);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&f.a[i]), bb, acc[i], 0, 0, 0);
+    };
     auto unpack = [&](const typename P::Raw & w, int ks) {
         Frags fr;
         if constexpr (T == T_Q6_K) P::unpack_h(w, h, fr.f);
         else                       P::unpack(w, ks, fr.f);
         return fr;
     };
-    auto compute = [&](const Frags fr, const uint8_t * stage) {
-#pragma unroll
-        for (int kk = 0; kk < NFRAG; ++kk) {
-            uint4 a[NA];
-#pragma unroll
-            for (int i = 0; i < NA; ++i) a[i] = *reinterpret_cast<const uint4 *>(stage + tile_off<BK>(32 * i + r, 2 * kk + h));
-            const f16x8 bb = *reinterpret_cast<const f16x8 *>(&fr.f[kk]);
-#pragma unroll
-            for (int i = 0; i < NA; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a[i]), bb, acc[i], 0, 0, 0);
-        }
-    };
 
-    // software pipeline: weight bytes two K-steps ahead in registers (even/odd slots), activation chunks two K-steps
-    // ahead in registers and one K-step ahead in LDS
+    // software pipeline: weight bytes two K-steps ahead in registers (even/odd slots), activation chunks two K-steps ahead
+    // in registers and one K-step ahead in LDS
     typename P::Raw w_e = P::load(wrow, ks0, h, K), w_o = P::load(wrow, ks0 + 1, h, K);
     XRegs x_e = load_x(ks0), x_o = load_x(ks0 + 1);
     store_x(x_e, lds);
     x_e = load_x(ks0 + 2);
-    __syncthreads();
 
-    for (int ks = ks0; ks < ks1; ks += 2) {
-        Frags fr = unpack(w_e, ks);
-        w_e = P::load(wrow, ks + 2, h, K);
-        store_x(x_o, lds + STAGE);  x_o = load_x(ks + 3);
-        compute(fr, lds);
+    if constexpr (NFRAG == 4) {
+        // The consumer and the pipeline of mfma_regb_q4k_kernel below (described there): B fragments one K-step ahead, the
+        // upper half of the workgroup's waves multiplies first and unpacks second, A-fragment reads one k-step ahead of
+        // the MFMAs.
+        auto compute = [&](const Frags fr, const uint8_t * stage) {
+            const AFr a0 = read_a(stage, 0 + h);
+            const AFr a1 = read_a(stage, 2 + h);
+            mfma_a(fr.f[0], a0);
+            const AFr a2 = read_a(stage, 4 + h);
+            mfma_a(fr.f[1], a1);
+            const AFr a3 = read_a(stage, 6 + h);
+            mfma_a(fr.f[2], a2);
+            mfma_a(fr.f[3], a3);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NA, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NA, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NA, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NA, 0);
+        };
+        Frags fr = unpack(w_e, ks0);
+        w_e = P::load(wrow, ks0 + 2, h, K);
         __syncthreads();
-        fr = unpack(w_o, ks + 1);
-        w_o = P::load(wrow, ks + 3, h, K);
-        store_x(x_e, lds);          x_e = load_x(ks + 4);
-        compute(fr, lds + STAGE);
+        auto run = [&](auto unpack_first) {
+            constexpr bool UF = decltype(unpack_first)::value;
+            for (int ks = ks0; ks < ks1; ks += 2) {
+                Frags frn;
+                if (UF) frn = unpack(w_o, ks + 1);
+                store_x(x_o, lds + STAGE);  x_o = load_x(ks + 3);
+                compute(fr, lds);
+                if (!UF) frn = unpack(w_o, ks + 1);
+                w_o = P::load(wrow, ks + 3, h, K);
+                __syncthreads();
+                fr = frn;
+                if (UF) frn = unpack(w_e, ks + 2);
+                store_x(x_e, lds);          x_e = load_x(ks + 4);
+                compute(fr, lds + STAGE);
+                if (!UF) frn = unpack(w_e, ks + 2);
+                w_e = P::load(wrow, ks + 4, h, K);
+                __syncthreads();
+                fr = frn;
+            }
+        };
+        if (NW >= 8 && wave >= NW / 2) run(std::false_type{});
+        else                           run(std::true_type{});
+    } else {
+        // Q6_K (eight fragments per K-step): the pipeline above does not fit the register file; unpack, then multiply
+        auto compute = [&](const Frags fr, const uint8_t * stage) {
+#pragma unroll
+            for (int kk = 0; kk < NFRAG; ++kk) mfma_a(fr.f[kk], read_a(stage, 2 * kk + h));
+        };
         __syncthreads();
+        for (int ks = ks0; ks < ks1; ks += 2) {
+            Frags fr = unpack(w_e, ks);
+            w_e = P::load(wrow, ks + 2, h, K);
+            store_x(x_o, lds + STAGE);  x_o = load_x(ks + 3);
+            compute(fr, lds);
+            __syncthreads();
+            fr = unpack(w_o, ks + 1);
+            w_o = P::load(wrow, ks + 3, h, K);
+            store_x(x_e, lds);          x_e = load_x(ks + 4);
+            compute(fr, lds + STAGE);
+            __syncthreads();
+        }
     }
 
     // epilogue: per-token scales / dst row offsets staged through LDS (all reads of the tiles are behind the last barrier).
