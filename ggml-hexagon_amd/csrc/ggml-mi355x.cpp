@@ -9,6 +9,7 @@
 //     (the reference re-maps tensor memory through FastRPC per call, ggml-hexagon.cpp:4975-5060);
 //   * op failures are reported as GGML_STATUS_FAILED (the reference logs and continues, :5053-5056);
 //   * consecutive MUL_MAT nodes that share src1 are issued as one grouped launch when the batch is <= 8.
+// Row split over the devices of this process (llama.cpp -sm row) is the split buffer type at the end of the file.
 //
 // This file includes only ggml headers and the C-ABI; all HIP lives in libggml_mi355x_qmm.so.
 
@@ -17,8 +18,11 @@
 #include "ggml-impl.h"
 #include "ggml_mi355x_qmm.h"
 
+#include <array>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -32,6 +36,13 @@ struct mi355x_device_ctx {
     std::string description;
     ggml_backend_buffer_type buft{};
     std::string buft_name;
+    // row split: staging for the copy of src1 and for this device's slice of dst when another device is the root of the op
+    void *      stage_x = nullptr;
+    size_t      stage_x_bytes = 0;
+    void *      stage_d = nullptr;
+    size_t      stage_d_bytes = 0;
+    qmm_event * ev_done = nullptr;       // this device's slice has landed in the root's dst
+    qmm_event * ev_ready = nullptr;      // (as root) src1 is ready on the root's stream
 };
 
 struct mi355x_buffer_ctx {
@@ -138,6 +149,128 @@ const ggml_backend_buffer_type_i buft_iface = {
     /* .is_host        = */ buft_is_host,
 };
 
+// ----------------------------------------------------------------------------------------------- split buffer type
+// ggml row split inside one process (ggml-cuda.cu:727-1052): a weight tensor's rows are divided over the devices by the
+// cumulative fractions of `tensor_split`, boundaries rounded down to 64 rows, the last device takes the remainder
+// (get_row_split :740-753; ggml-hexagon_amd/rowsplit.py is the same rule for the one-process-per-GPU path).  The buffer
+// owns one allocation per (tensor, device); tensor->data is a dummy and tensor->extra points at the slices.
+// Only whole-tensor set_tensor / get_tensor, as in the reference (:800-885).
+
+constexpr int64_t SPLIT_ROW_ROUNDING = 64;
+
+struct split_buft_ctx {
+    int         main_device;
+    std::array<float, GGML_MI355X_MAX_DEVICES> split;     // cumulative start fraction per device
+    std::string name;
+};
+struct split_extra {
+    void *  data[GGML_MI355X_MAX_DEVICES] = {};
+    int64_t lo[GGML_MI355X_MAX_DEVICES] = {}, hi[GGML_MI355X_MAX_DEVICES] = {};
+};
+struct split_buffer_ctx {
+    std::vector<split_extra *> extras;
+};
+
+void split_row_range(const split_buft_ctx * c, int64_t nrows, int id, int64_t * lo, int64_t * hi) {
+    *lo = id == 0 ? 0 : (int64_t) (nrows * c->split[id]);
+    *lo -= *lo % SPLIT_ROW_ROUNDING;
+    if (id == g_ndev - 1) {
+        *hi = nrows;
+    } else {
+        *hi = (int64_t) (nrows * c->split[id + 1]);
+        *hi -= *hi % SPLIT_ROW_ROUNDING;
+    }
+    if (*hi < *lo) *hi = *lo;
+}
+
+const char * split_buft_get_name(ggml_backend_buffer_type_t buft) { return ((split_buft_ctx *) buft->context)->name.c_str(); }
+bool buft_is_split(ggml_backend_buffer_type_t buft) { return buft->iface.get_name == split_buft_get_name; }
+
+void split_buffer_free(ggml_backend_buffer_t buffer) {
+    auto * ctx = (split_buffer_ctx *) buffer->context;
+    for (split_extra * e : ctx->extras) {
+        for (int id = 0; id < g_ndev; ++id)
+            if (e->data[id]) qmm_free(g_devs[id].qmm, e->data[id]);
+        delete e;
+    }
+    delete ctx;
+}
+void * split_buffer_get_base(ggml_backend_buffer_t) { return (void *) 0x1000; }      // never dereferenced (ggml-cuda.cu:793-798)
+
+enum ggml_status split_buffer_init_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor) {
+    GGML_ASSERT(tensor->view_src == nullptr);                      // views of split tensors are not supported (:803)
+    GGML_ASSERT(ggml_is_contiguous(tensor) && tensor->ne[2] == 1 && tensor->ne[3] == 1);
+    auto * ctx  = (split_buffer_ctx *) buffer->context;
+    auto * bctx = (split_buft_ctx *) buffer->buft->context;
+    auto * e = new split_extra;
+    ctx->extras.push_back(e);
+    const size_t row_bytes = ggml_row_size(tensor->type, tensor->ne[0]);
+    for (int id = 0; id < g_ndev; ++id) {
+        split_row_range(bctx, tensor->ne[1], id, &e->lo[id], &e->hi[id]);
+        const int64_t rows = e->hi[id] - e->lo[id];
+        if (rows == 0) continue;
+        e->data[id] = qmm_malloc(g_devs[id].qmm, rows * row_bytes + 256);
+        if (!e->data[id]) {
+            GGML_LOG_ERROR("%s: %s: %.2f MiB on %s: %s\n", __func__, tensor->name, rows * row_bytes / 1048576.0, g_devs[id].name.c_str(), qmm_last_error());
+            return GGML_STATUS_ALLOC_FAILED;
+        }
+    }
+    tensor->extra = e;
+    return GGML_STATUS_SUCCESS;
+}
+void split_buffer_set_tensor(ggml_backend_buffer_t, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    GGML_ASSERT(offset == 0 && size == ggml_nbytes(tensor));      // split tensors are set in one go (:839-841)
+    auto * e = (split_extra *) tensor->extra;
+    const size_t row_bytes = ggml_row_size(tensor->type, tensor->ne[0]);
+    for (int id = 0; id < g_ndev; ++id) {
+        if (!e->data[id]) continue;
+        if (qmm_memcpy_h2d(g_devs[id].qmm, e->data[id], (const char *) data + e->lo[id] * row_bytes, (e->hi[id] - e->lo[id]) * row_bytes, nullptr))
+            GGML_ABORT("MI355X split set_tensor: %s", qmm_last_error());
+    }
+}
+void split_buffer_get_tensor(ggml_backend_buffer_t, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    GGML_ASSERT(offset == 0 && size == ggml_nbytes(tensor));
+    auto * e = (split_extra *) tensor->extra;
+    const size_t row_bytes = ggml_row_size(tensor->type, tensor->ne[0]);
+    for (int id = 0; id < g_ndev; ++id) {
+        if (!e->data[id]) continue;
+        if (qmm_memcpy_d2h(g_devs[id].qmm, (char *) data + e->lo[id] * row_bytes, e->data[id], (e->hi[id] - e->lo[id]) * row_bytes, nullptr))
+            GGML_ABORT("MI355X split get_tensor: %s", qmm_last_error());
+    }
+}
+void split_buffer_clear(ggml_backend_buffer_t, uint8_t) {}
+
+const ggml_backend_buffer_i split_buffer_iface = {
+    /* .free_buffer   = */ split_buffer_free,
+    /* .get_base      = */ split_buffer_get_base,
+    /* .init_tensor   = */ split_buffer_init_tensor,
+    /* .memset_tensor = */ nullptr,
+    /* .set_tensor    = */ split_buffer_set_tensor,
+    /* .get_tensor    = */ split_buffer_get_tensor,
+    /* .cpy_tensor    = */ nullptr,
+    /* .clear         = */ split_buffer_clear,
+    /* .reset         = */ nullptr,
+};
+
+ggml_backend_buffer_t split_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    // the slices are allocated per tensor in init_tensor; `size` only keeps ggml-alloc's offsets apart (:948-956)
+    return ggml_backend_buffer_init(buft, split_buffer_iface, new split_buffer_ctx, size);
+}
+size_t split_buft_get_alignment(ggml_backend_buffer_type_t) { return 128; }
+size_t split_buft_get_alloc_size(ggml_backend_buffer_type_t, const struct ggml_tensor * tensor) {
+    return ggml_nbytes(tensor) + (size_t) 256 * GGML_MI355X_MAX_DEVICES;
+}
+bool split_buft_is_host(ggml_backend_buffer_type_t) { return false; }
+
+const ggml_backend_buffer_type_i split_buft_iface = {
+    /* .get_name       = */ split_buft_get_name,
+    /* .alloc_buffer   = */ split_buft_alloc_buffer,
+    /* .get_alignment  = */ split_buft_get_alignment,
+    /* .get_max_size   = */ nullptr,
+    /* .get_alloc_size = */ split_buft_get_alloc_size,
+    /* .is_host        = */ split_buft_is_host,
+};
+
 // ----------------------------------------------------------------------------------------------- ops
 
 bool is_ours(const struct ggml_tensor * t) {
@@ -157,9 +290,12 @@ bool mul_mat_shape_ok(const struct ggml_tensor * op) {
     return true;
 }
 
+bool is_split(const struct ggml_tensor * t) { return t->buffer && buft_is_split(t->buffer->buft); }
+
 bool supports_mul_mat(const struct ggml_tensor * op) {
     if (!mul_mat_shape_ok(op)) return false;
     const ggml_tensor * a = op->src[0], * b = op->src[1];
+    if (is_split(a) && (a->ne[2] != 1 || a->ne[3] != 1 || b->ne[2] != 1 || b->ne[3] != 1)) return false;
     if (b->nb[1] < b->ne[0] * sizeof(float)) return false;                          // transposed / permuted src1
     if (b->ne[2] % a->ne[2] || b->ne[3] % a->ne[3]) return false;
     if (a->nb[2] < a->nb[1] * (size_t) a->ne[1] || (a->ne[3] > 1 && a->nb[3] < a->nb[2] * (size_t) a->ne[2])) return false;   // permuted src0
@@ -169,6 +305,7 @@ bool supports_mul_mat(const struct ggml_tensor * op) {
 bool supports_mul_mat_id(const struct ggml_tensor * op) {
     const ggml_tensor * as = op->src[0], * b = op->src[1], * ids = op->src[2];
     if (!mul_mat_shape_ok(op) || !ids || ids->type != GGML_TYPE_I32) return false;
+    if (is_split(as)) return false;                                                // as in the reference tree (ggml-cuda.cu:1973)
     if (as->ne[3] != 1 || b->ne[3] != 1 || ids->ne[2] != 1 || ids->ne[3] != 1) return false;
     if (ids->nb[0] != sizeof(int32_t) || ids->nb[1] % 4) return false;
     if (b->ne[1] != 1 && b->ne[1] != ids->ne[0]) return false;                     // ne11 broadcast rule (ggml.c:2781-2808)
@@ -177,12 +314,66 @@ bool supports_mul_mat_id(const struct ggml_tensor * op) {
     return true;
 }
 
+bool grow(mi355x_device_ctx * d, void *& p, size_t & have, size_t need) {
+    if (need <= have) return true;
+    if (qmm_synchronize(d->qmm, qmm_stream(d->qmm))) return false;                 // queued work may still read the old block
+    if (p) qmm_free(d->qmm, p);
+    have = 0;
+    need = (need + ((size_t) 8 << 20) - 1) & ~(((size_t) 8 << 20) - 1);
+    p = qmm_malloc(d->qmm, need);
+    if (!p) return false;
+    have = need;
+    return true;
+}
+
+// MUL_MAT with row-split src0 (ggml_cuda_op_mul_mat, ggml-cuda.cu:1365-1673).  The device running the node is the root: it
+// holds src1 and dst.  The root computes its rows straight into dst[:, lo:hi]; every other device copies src1 over the
+// fabric, computes its rows into a staging slice and copies that into the root's dst (N runs of `rows` floats).  All of it
+// is stream-ordered: devices wait for the root's "src1 ready" event, the root waits for each device's "slice landed".
+// The exchange is a concat, so there is no reduction and the result does not depend on the number of devices.
+enum ggml_status compute_mul_mat_split(mi355x_backend_ctx * ctx, const ggml_tensor * dst) {
+    const ggml_tensor * a = dst->src[0], * b = dst->src[1];
+    auto * e = (const split_extra *) a->extra;
+    mi355x_device_ctx * root = ctx->dev;
+    void * rst = qmm_stream(root->qmm);
+    const int64_t K = a->ne[0], N = b->ne[1], ldx = b->nb[1] / sizeof(float), ldd = dst->nb[1] / sizeof(float);
+    if (!root->ev_ready) root->ev_ready = qmm_event_create(root->qmm);
+    if (!root->ev_ready || qmm_event_record(root->qmm, root->ev_ready, rst)) goto fail;
+    for (int id = 0; id < g_ndev; ++id) {
+        const int64_t rows = e->hi[id] - e->lo[id];
+        if (rows == 0) continue;
+        mi355x_device_ctx * d = &g_devs[id];
+        if (d == root) {
+            if (qmm_mul_mat(root->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) b->data, N, ldx,
+                            (float *) dst->data + e->lo[id], ldd, rst)) goto fail;
+            continue;
+        }
+        void * st = qmm_stream(d->qmm);
+        if (!d->ev_done) d->ev_done = qmm_event_create(d->qmm);
+        if (!d->ev_done || !grow(d, d->stage_x, d->stage_x_bytes, (size_t) N * K * sizeof(float)) ||
+            !grow(d, d->stage_d, d->stage_d_bytes, (size_t) N * rows * sizeof(float))) goto fail;
+        if (qmm_stream_wait_event(d->qmm, st, root->ev_ready) ||
+            qmm_memcpy2d_d2d(d->qmm, d->stage_x, K * sizeof(float), b->data, b->nb[1], K * sizeof(float), N, st) ||
+            qmm_mul_mat(d->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) d->stage_x, N, K,
+                        (float *) d->stage_d, rows, st) ||
+            qmm_memcpy2d_d2d(d->qmm, (float *) dst->data + e->lo[id], dst->nb[1], d->stage_d, rows * sizeof(float),
+                             rows * sizeof(float), N, st) ||
+            qmm_event_record(d->qmm, d->ev_done, st) ||
+            qmm_stream_wait_event(root->qmm, rst, d->ev_done)) goto fail;
+    }
+    return GGML_STATUS_SUCCESS;
+fail:
+    GGML_LOG_ERROR("MI355X MUL_MAT(%s) row split: %s\n", dst->name, qmm_last_error());
+    return GGML_STATUS_FAILED;
+}
+
 enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, const ggml_tensor * const * nodes, int n_nodes, int * consumed) {
     const ggml_tensor * dst = nodes[0];
     const ggml_tensor * a = dst->src[0], * b = dst->src[1];
     qmm_ctx * q = ctx->dev->qmm;
     void * st = qmm_stream(q);
     *consumed = 1;
+    if (is_split(a)) return compute_mul_mat_split(ctx, dst);
     const int64_t K = a->ne[0], N = b->ne[1];
     const bool flat = a->ne[2] == 1 && a->ne[3] == 1 && b->ne[2] == 1 && b->ne[3] == 1;
     if (flat) {
@@ -331,6 +522,7 @@ bool dev_supports_op(ggml_backend_dev_t, const struct ggml_tensor * op) {
     }
 }
 bool dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    if (buft_is_split(buft)) return true;                             // any device can be the root of a split MUL_MAT
     return buft->iface.get_name == buft_get_name && buft->context == dev->context;
 }
 
@@ -357,9 +549,30 @@ const ggml_backend_device_i device_iface = {
 const char * reg_get_name(ggml_backend_reg_t) { return GGML_MI355X_BACKEND_NAME; }
 size_t reg_get_device_count(ggml_backend_reg_t) { return (size_t) g_ndev; }
 ggml_backend_dev_t reg_get_device(ggml_backend_reg_t, size_t index) { return index < (size_t) g_ndev ? &g_devices[index] : nullptr; }
-void * reg_get_proc_address(ggml_backend_reg_t, const char *) {
-    // "ggml_backend_split_buffer_type" is not exported yet: llama.cpp then falls back to layer split
-    // (src/llama-model.cpp:316-346).  Row split lives in the one-process-per-GPU path (rowsplit.py) this round.
+// tensor_split: per-device proportions as llama.cpp passes them (src/llama-model.cpp:316-346); all zero or NULL = equal
+// shares.  Cached per (main_device, fractions) like ggml_backend_cuda_split_buffer_type (ggml-cuda.cu:1010-1052).
+ggml_backend_buffer_type_t split_buffer_type(int main_device, const float * tensor_split) {
+    static std::mutex mutex;
+    std::lock_guard<std::mutex> lock(mutex);
+    static std::map<std::pair<int, std::array<float, GGML_MI355X_MAX_DEVICES>>, ggml_backend_buffer_type> bufts;
+    if (main_device < 0 || main_device >= g_ndev) return nullptr;
+    std::array<float, GGML_MI355X_MAX_DEVICES> cum = {};
+    float sum = 0.0f;
+    for (int i = 0; i < g_ndev; ++i) sum += tensor_split ? tensor_split[i] : 0.0f;
+    float acc = 0.0f;
+    for (int i = 0; i < g_ndev; ++i) {
+        cum[i] = sum > 0.0f ? acc / sum : (float) i / g_ndev;
+        acc += tensor_split ? tensor_split[i] : 0.0f;
+    }
+    auto key = std::make_pair(main_device, cum);
+    auto it = bufts.find(key);
+    if (it != bufts.end()) return &it->second;
+    auto * ctx = new split_buft_ctx{ main_device, cum, std::string(GGML_MI355X_BACKEND_NAME) + std::to_string(main_device) + "_Split" };
+    return &bufts.emplace(key, ggml_backend_buffer_type{ split_buft_iface, &g_devices[main_device], ctx }).first->second;
+}
+
+void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
+    if (strcmp(name, "ggml_backend_split_buffer_type") == 0) return (void *) split_buffer_type;    // llama.cpp -sm row
     return nullptr;
 }
 
@@ -373,15 +586,19 @@ ggml_backend_reg_t ggml_backend_mi355x_reg(void) {
     static ggml_backend_reg reg = { GGML_BACKEND_API_VERSION, reg_iface, nullptr };
     static std::once_flag once;                                     // the reference guards its reg init too (ggml-hexagon.cpp:5953-5955)
     std::call_once(once, [] {
-        const int n = qmm_device_count();
+        const int n_phys = qmm_device_count();
+        // GGML_MI355X_VIRTUAL_DEVICES=n registers n logical devices over the physical ones (round robin): lets the row split
+        // be exercised on a one-GPU box (tests/test_gpu_split_buffer.py); each logical device has its own context and stream
+        const char * vd = getenv("GGML_MI355X_VIRTUAL_DEVICES");
+        const int n = vd && atoi(vd) > 0 && n_phys > 0 ? atoi(vd) : n_phys;
         for (int i = 0; i < n && g_ndev < GGML_MI355X_MAX_DEVICES; ++i) {
-            qmm_ctx * q = qmm_create(i);
+            qmm_ctx * q = qmm_create(i % n_phys);
             if (!q) {
                 GGML_LOG_WARN("MI355X: skipping HIP device %d: %s\n", i, qmm_last_error());
                 continue;
             }
             mi355x_device_ctx & d = g_devs[g_ndev];
-            d.ordinal = i;
+            d.ordinal = i % n_phys;
             d.qmm = q;
             d.name = std::string(GGML_MI355X_BACKEND_NAME) + std::to_string(g_ndev);
             char nm[128] = { 0 };

@@ -121,6 +121,14 @@ qmm_ctx * qmm_create(int device) {
         delete c;
         return nullptr;
     }
+    for (int j = 0; j < n; ++j) {                                   // row split copies between devices: peer access, best effort
+        int can = 0;
+        if (j != device && hipDeviceCanAccessPeer(&can, device, j) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(j, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void) hipGetLastError();
+        }
+    }
+    (void) hipGetLastError();
     const char * e = getenv("GGML_MI355X_SPLITK");
     if (e) c->splitk = atoi(e);
     e = getenv("GGML_MI355X_ACT_MODE");
@@ -204,6 +212,43 @@ int qmm_memcpy_d2h(qmm_ctx * c, void * dst, const void * src, size_t n, void * s
 int qmm_memcpy_d2d(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->s(st)));
+    return QMM_OK;
+}
+int qmm_memcpy2d_d2d(qmm_ctx * c, void * dst, size_t dpitch, const void * src, size_t spitch, size_t width, size_t height, void * st) {
+    if (!c) return fail(QMM_EINVAL, "null ctx");
+    if (width == 0 || height == 0) return QMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (dpitch == width && spitch == width) HIP_TRY(hipMemcpyAsync(dst, src, width * height, hipMemcpyDeviceToDevice, c->s(st)));
+    else HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, c->s(st)));
+    return QMM_OK;
+}
+struct qmm_event { hipEvent_t ev; };
+qmm_event * qmm_event_create(qmm_ctx * c) {
+    if (!c || hipSetDevice(c->device) != hipSuccess) { fail(QMM_EINVAL, "qmm_event_create: bad ctx"); return nullptr; }
+    qmm_event * e = new qmm_event;
+    if (hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) != hipSuccess) {
+        fail(QMM_EHIP, "qmm_event_create: hipEventCreate failed");
+        delete e;
+        return nullptr;
+    }
+    return e;
+}
+void qmm_event_destroy(qmm_ctx * c, qmm_event * e) {
+    if (!e) return;
+    if (c) (void) hipSetDevice(c->device);
+    (void) hipEventDestroy(e->ev);
+    delete e;
+}
+int qmm_event_record(qmm_ctx * c, qmm_event * e, void * st) {
+    if (!c || !e) return fail(QMM_EINVAL, "qmm_event_record: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(e->ev, c->s(st)));
+    return QMM_OK;
+}
+int qmm_stream_wait_event(qmm_ctx * c, void * st, qmm_event * e) {
+    if (!c || !e) return fail(QMM_EINVAL, "qmm_stream_wait_event: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamWaitEvent(c->s(st), e->ev, 0));
     return QMM_OK;
 }
 int qmm_memset(qmm_ctx * c, void * dst, int v, size_t n, void * st) {

@@ -88,6 +88,19 @@ QMM_API int          qmm_memcpy_d2d(qmm_ctx * ctx, void * dst, const void * src,
 QMM_API int          qmm_memset(qmm_ctx * ctx, void * dst, int value, size_t bytes, void * stream);
 QMM_API int          qmm_synchronize(qmm_ctx * ctx, void * stream);
 
+/* Cross-device plumbing for the row split (one process, several devices: ggml-cuda.cu:1365-1673 does the same with
+ * cudaMemcpyPeerAsync / cudaMemcpy2DAsync and cudaEvents).  A copy may name memory of any device of this process
+ * (qmm_create enables peer access between all gfx950 devices it can); it runs on `stream`, which belongs to `ctx`.
+ * qmm_memcpy2d_d2d copies `height` runs of `width` bytes, the runs `dpitch` / `spitch` bytes apart.
+ * Events order streams of different contexts: record on one, wait on another. */
+typedef struct qmm_event qmm_event;
+QMM_API int          qmm_memcpy2d_d2d(qmm_ctx * ctx, void * dst, size_t dpitch, const void * src, size_t spitch,
+                                      size_t width, size_t height, void * stream);
+QMM_API qmm_event *  qmm_event_create(qmm_ctx * ctx);
+QMM_API void         qmm_event_destroy(qmm_ctx * ctx, qmm_event * ev);
+QMM_API int          qmm_event_record(qmm_ctx * ctx, qmm_event * ev, void * stream);
+QMM_API int          qmm_stream_wait_event(qmm_ctx * ctx, void * stream, qmm_event * ev);
+
 QMM_API size_t       qmm_row_size(int type, int64_t k);
 
 /* dst f32 [rows, K] (contiguous) = bit-exact unpack of `rows` weight rows */

@@ -1,0 +1,32 @@
+"""Row split inside the plugin: tests/cpp/test_split_buffer.cpp, linked against the reference's own ggml
+libraries (oracle/_ref), asks the module for "ggml_backend_split_buffer_type" the way llama.cpp does with -sm row, puts
+weights in it and runs MUL_MAT on the root device; results are compared with the ggml CPU backend (NMSE <= 5e-4) and
+with the unsplit product on one device (bit for bit at N <= 8).  A one-GPU box has one device, so the module is told to
+register several logical devices over it (GGML_MI355X_VIRTUAL_DEVICES): every slice allocation, cross-"device" copy,
+event wait and 2-D gather of the real multi-GPU path runs, only the fabric under the copies differs."""
+import os
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+EXE = ROOT / "oracle" / "_ref" / "test-split-buffer"
+PLUGIN = ROOT / "ggml-hexagon_amd" / "libggml-mi355x.so"
+
+
+@pytest.mark.parametrize("n_virtual", [2, 3])
+def test_row_split_matches_cpu_and_unsplit(n_virtual):
+    if not EXE.exists() or not PLUGIN.exists():
+        pytest.skip("oracle/_ref/test-split-buffer or the plugin module is not built (needs the reference tree at build time)")
+    env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN), GGML_MI355X_VIRTUAL_DEVICES=str(n_virtual))
+    p = subprocess.run([str(EXE)], env=env, capture_output=True, text=True, timeout=900, cwd=str(EXE.parent))
+    out = p.stdout + p.stderr
+    assert f"MI355X devices: {n_virtual}" in out, out[-2000:]
+    fails = [l for l in out.splitlines() if l.rstrip().endswith("FAIL")]
+    assert not fails, "\n".join(fails[:20])
+    m = re.search(r"(\d+) OK, (\d+) FAILED", out)
+    assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) >= 200, out[-3000:]
