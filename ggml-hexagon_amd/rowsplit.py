@@ -39,6 +39,16 @@ class RowConcat:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self._stage = {}          # staging buffers by (rows, cols, dtype, device): allocated once, the exchange runs per MUL_MAT group
+
+    def _buf(self, rows, cols, like, zero=False):
+        import torch
+        key = (rows, cols, like.dtype, like.device, zero)
+        b = self._stage.get(key)
+        if b is None:
+            b = (torch.zeros if zero else torch.empty)((rows, cols), dtype=like.dtype, device=like.device)
+            self._stage[key] = b
+        return b
 
     def concat(self, local, ranges, out=None):
         import torch
@@ -50,17 +60,21 @@ class RowConcat:
         if self.world == 1:
             out.copy_(local)
             return out
-        if len(set(sizes)) == 1 and local.is_contiguous():
-            stage = torch.empty((self.world * n, sizes[0]), dtype=local.dtype, device=local.device)
+        equal = len(set(sizes)) == 1 and local.is_contiguous()
+        if equal and n == 1 and out.is_contiguous():
+            # one token (token generation): [world, rows] in rank order IS dst; gather straight into it
+            self.dist.all_gather_into_tensor(out.view(self.world, sizes[0]), local, group=self.group)
+        elif equal:
+            stage = self._buf(self.world * n, sizes[0], local)
             self.dist.all_gather_into_tensor(stage, local, group=self.group)
             out.view(n, self.world, sizes[0]).copy_(stage.view(self.world, n, sizes[0]).permute(1, 0, 2))
         else:
             # ragged slices (ggml gives the remainder rows to the last device): pad to the widest slice so that one
             # equal-size all-gather still does the exchange, then drop the padding while concatenating
             smax = max(sizes)
-            padded = torch.zeros((n, smax), dtype=local.dtype, device=local.device)
+            padded = self._buf(n, smax, local, zero=True)
             padded[:, :local.shape[1]] = local
-            stage = torch.empty((self.world * n, smax), dtype=local.dtype, device=local.device)
+            stage = self._buf(self.world * n, smax, local)
             self.dist.all_gather_into_tensor(stage, padded, group=self.group)
             stage = stage.view(self.world, n, smax)
             for r, (lo, hi) in enumerate(ranges):
