@@ -27,8 +27,12 @@
  *     Calls are asynchronous on that stream; nothing synchronizes except qmm_synchronize / qmm_memcpy_h2d/_d2h;
  *   - `type` is ggml's enum ggml_type value: Q4_0=2, Q8_0=8, Q4_K=12, Q5_K=13, Q6_K=14;
  *   - weights are in GGUF wire layout: rows of blocks, `w_row_bytes` apart (>= K/blck*type_size);
- *   - returns 0 on success, a negative QMM_E* code otherwise (qmm_last_error() has the text).
- *     Nothing falls back to the CPU.
+ *   - returns 0 on success, a negative QMM_E* code otherwise (qmm_last_error() has the text, per thread).
+ *     Nothing falls back to the CPU;
+ *   - a context owns one scratch workspace (prefill operands, split-K partial tiles, MoE lists): issue its compute
+ *     calls from one thread and on one stream at a time.  The workspace grows on demand, which synchronizes the
+ *     device: run a shape once before capturing it into a hipGraph.  Several contexts per device are fine (the
+ *     plugin's logical devices each have their own).
  */
 #ifndef GGML_MI355X_QMM_H
 #define GGML_MI355X_QMM_H

@@ -326,3 +326,23 @@ def test_strided_operands(qmm, oracle, n):
         assert (o[:, m:] == 5.0).all()
         want = oracle.mul_mat(t, w, k, x, ACT_REF)
         assert (rel_rms(o[:, :m], want) < 2e-5) if n <= 8 else (rel_l2(o[:, :m], want) < 1e-3)
+
+
+@pytest.mark.parametrize("t", (Q4_K, Q6_K, Q8_0), ids=["q4_K", "q6_K", "q8_0"])
+def test_splitk_prefill_strided_dst_and_ragged_rows(qmm, oracle, t):
+    """few tiles + long K: the tiled kernel splits K over workgroups and splitk_reduce_kernel writes dst — here with a
+    row count that is not a multiple of the tile or of 4 (scalar reduce path) and dst rows ldd > M apart (M % 4 == 0:
+    the float4 path), against the oracle; the result must also be the same on a second run (fixed summation order)"""
+    import ggml_hexagon_amd.synth as synth
+    for m, k, n in ((300, 2048, 300), (253, 1536, 270)):      # N > 256: past the few-token kernel
+        w = synth.synth_weights(t, m, k, seed=m + k, sigma=0.2)
+        x = np.random.default_rng(m).uniform(-1, 1, (n, k)).astype(np.float32)
+        out = torch.full((n, m + 12), 7.0, device="cuda")
+        qmm.mul_mat(t, dev(w), k, dev(x), out=out[:, :m])
+        first = out.cpu().numpy().copy()
+        out.fill_(7.0)
+        qmm.mul_mat(t, dev(w), k, dev(x), out=out[:, :m])
+        o = out.cpu().numpy()
+        assert (o[:, m:] == 7.0).all()
+        assert np.array_equal(o, first)
+        assert rel_l2(o[:, :m], oracle.mul_mat(t, w, k, x, ACT_REF)) < 1e-3
