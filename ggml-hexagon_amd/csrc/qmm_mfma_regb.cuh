@@ -829,7 +829,7 @@ inline int launch_mfma_regb_t(qmm_ctx * c, hipStream_t st, const void * W, int64
     if (op.frag_major && N <= 32) QMM_SKINNY(8, 1);           // (16 waves per group measured no better, Q6_K worse)
     else if (op.frag_major)       QMM_SKINNY(8, 2);
     else if (ksplit > 1 || wg_256 * 10 >= (int64_t) c->cus * 8) QMM_REGB(8, 128, 256, n_tiles_y);
-    else if (wg_128 >= c->cus)              QMM_REGB(4, 128, 128, n_tiles_y);
+    else if (wg_128 >= c->cus && T != T_Q6_K) QMM_REGB(4, 128, 128, n_tiles_y);   // (Q6_K: this shape spills, 4.5x slower)
     else if (2 * wg_128 >= c->cus / 2)       QMM_REGB(4, 64, 128, 2 * n_tiles_y);
     else                                     QMM_REGB(4, 32, 128, 4 * n_tiles_y);
 #undef QMM_REGB
