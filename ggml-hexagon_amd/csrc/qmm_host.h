@@ -21,7 +21,7 @@ struct qmm_ctx {
     int         mv_bpc = 1;          // mat-vec blocks per CU (tuning knob, GGML_MI355X_MV_BPC)
     int         skinny = 1;          // few-token split-K MFMA kernel (GGML_MI355X_SKINNY=0 turns it off)
     int         skinny_max_n = 64;   // ... used for 8 < N <= this, and up to skinny_max_n_few when the matrix has no more
-    int         skinny_max_n_few = 256;  //     32-row groups than the chip has CUs (GGML_MI355X_SKINNY_MAXN sets both)
+    int         skinny_max_n_few = 128;  //     32-row groups than the chip has CUs (GGML_MI355X_SKINNY_MAXN sets both)
     // workspace of the batched path (16-bit activations, row scales, MoE lists); grown on demand
     void *      ws = nullptr;
     size_t      ws_bytes = 0;

@@ -500,8 +500,8 @@ inline int launch_mfma(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, 
 
 bool mfma_regb_supports(const qmm_ctx * c, int type);
 // few tokens: the split-K kernel of qmm_mfma_regb.cuh, which wants the operand fragment-major
-// (measured on MI355X: it wins up to 64 tokens on any matrix, and up to 256 tokens on matrices of <= 8192 rows, which give
-// the tiled kernels too few workgroups to fill the chip)
+// (measured on MI355X: it wins up to 64 tokens on any matrix, and up to 128 tokens on matrices of <= 8192 rows, which give
+// the tiled kernels too few workgroups to fill the chip; from 129 tokens the tiled kernel with split-K is level or ahead)
 inline bool mfma_use_skinny(const qmm_ctx * c, int type, int64_t N, int64_t M, int64_t n_expert = 1) {
     if (!mfma_regb_supports(c, type) || !c->skinny) return false;
     return N <= c->skinny_max_n || (N <= c->skinny_max_n_few && (M + 31) / 32 * n_expert <= c->cus);

@@ -334,7 +334,7 @@ def test_splitk_prefill_strided_dst_and_ragged_rows(qmm, oracle, t):
     row count that is not a multiple of the tile or of 4 (scalar reduce path) and dst rows ldd > M apart (M % 4 == 0:
     the float4 path), against the oracle; the result must also be the same on a second run (fixed summation order)"""
     import ggml_hexagon_amd.synth as synth
-    for m, k, n in ((300, 2048, 300), (253, 1536, 270)):      # N > 256: past the few-token kernel
+    for m, k, n in ((300, 2048, 300), (253, 1536, 270)):      # N > 128: past the few-token kernel
         w = synth.synth_weights(t, m, k, seed=m + k, sigma=0.2)
         x = np.random.default_rng(m).uniform(-1, 1, (n, k)).astype(np.float32)
         out = torch.full((n, m + 12), 7.0, device="cuda")
