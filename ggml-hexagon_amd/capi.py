@@ -16,7 +16,8 @@ EXPORTS = [
     "qmm_abi_version", "qmm_last_error", "qmm_device_count", "qmm_create", "qmm_destroy", "qmm_device", "qmm_stream",
     "qmm_device_info", "qmm_set_act_mode", "qmm_set_precision", "qmm_malloc", "qmm_free", "qmm_memcpy_h2d",
     "qmm_memcpy_d2h", "qmm_memcpy_d2d", "qmm_memset", "qmm_synchronize", "qmm_memcpy2d_d2d", "qmm_event_create",
-    "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_row_size", "qmm_dequantize",
+    "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_memcpy_h2d_async",
+    "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_dequantize",
     "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_id",
 ]
 
@@ -57,6 +58,9 @@ def load_library() -> C.CDLL:
     lib.qmm_event_destroy.argtypes = [v, v]
     lib.qmm_event_record.argtypes = [v, v, v]
     lib.qmm_stream_wait_event.argtypes = [v, v, v]
+    lib.qmm_event_synchronize.argtypes = [v, v]
+    lib.qmm_memcpy_h2d_async.argtypes = [v, v, v, sz, v]
+    lib.qmm_memcpy_d2h_async.argtypes = [v, v, v, sz, v]
     lib.qmm_row_size.restype = sz
     lib.qmm_row_size.argtypes = [i32, i64]
     lib.qmm_dequantize.argtypes = [v, i32, v, i64, i64, i64, v, v]

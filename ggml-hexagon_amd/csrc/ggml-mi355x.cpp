@@ -53,6 +53,7 @@ struct mi355x_buffer_ctx {
 struct mi355x_backend_ctx {
     mi355x_device_ctx * dev;
     std::string         name;
+    qmm_event *         ev_copy = nullptr;   // cpy_tensor_async: "src is ready" on the source backend's stream
 };
 
 mi355x_device_ctx      g_devs[GGML_MI355X_MAX_DEVICES];
@@ -430,8 +431,57 @@ enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, const ggml_tensor 
 const char * backend_get_name(ggml_backend_t backend) { return ((mi355x_backend_ctx *) backend->context)->name.c_str(); }
 
 void backend_free(ggml_backend_t backend) {
-    delete (mi355x_backend_ctx *) backend->context;
+    auto * ctx = (mi355x_backend_ctx *) backend->context;
+    if (ctx->ev_copy) qmm_event_destroy(ctx->dev->qmm, ctx->ev_copy);
+    delete ctx;
     delete backend;
+}
+
+// ---- asynchronous transfers and events: everything a backend does is ordered on its context's stream, so
+// these are the stream-ordered forms of set/get/cpy (ggml-backend-impl.h:93-95) and record/wait (:114-116).
+// graph_compute itself still ends with a stream synchronize (that is where a bad expert id is reported).
+bool on_device(const struct ggml_tensor * t, const mi355x_device_ctx * dev) {
+    ggml_backend_buffer_t b = t->view_src ? t->view_src->buffer : t->buffer;
+    return b && b->buft->iface.get_name == buft_get_name && b->buft->context == (void *) dev;
+}
+void backend_set_tensor_async(ggml_backend_t backend, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    auto * ctx = (mi355x_backend_ctx *) backend->context;
+    GGML_ASSERT(on_device(tensor, ctx->dev) && "set_tensor_async: tensor is not in this device's buffer type");
+    if (qmm_memcpy_h2d_async(ctx->dev->qmm, (char *) tensor->data + offset, data, size, qmm_stream(ctx->dev->qmm)))
+        GGML_ABORT("MI355X set_tensor_async: %s", qmm_last_error());
+}
+void backend_get_tensor_async(ggml_backend_t backend, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    auto * ctx = (mi355x_backend_ctx *) backend->context;
+    GGML_ASSERT(on_device(tensor, ctx->dev) && "get_tensor_async: tensor is not in this device's buffer type");
+    if (qmm_memcpy_d2h_async(ctx->dev->qmm, data, (const char *) tensor->data + offset, size, qmm_stream(ctx->dev->qmm)))
+        GGML_ABORT("MI355X get_tensor_async: %s", qmm_last_error());
+}
+ggml_guid_t backend_guid();
+bool backend_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backend_dst, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    if (!ggml_guid_matches(backend_src->guid, backend_guid()) || !ggml_guid_matches(backend_dst->guid, backend_guid())) return false;
+    auto * sctx = (mi355x_backend_ctx *) backend_src->context;
+    auto * dctx = (mi355x_backend_ctx *) backend_dst->context;
+    if (!on_device(src, sctx->dev) || !on_device(dst, dctx->dev) || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst)) return false;
+    qmm_ctx * dq = dctx->dev->qmm;
+    void * dst_stream = qmm_stream(dq);
+    if (sctx->dev != dctx->dev) {            // the copy runs on the destination's stream, behind what the source has queued
+        if (!sctx->ev_copy) sctx->ev_copy = qmm_event_create(sctx->dev->qmm);
+        if (!sctx->ev_copy || qmm_event_record(sctx->dev->qmm, sctx->ev_copy, qmm_stream(sctx->dev->qmm)) ||
+            qmm_stream_wait_event(dq, dst_stream, sctx->ev_copy))
+            GGML_ABORT("MI355X cpy_tensor_async: %s", qmm_last_error());
+    }
+    if (qmm_memcpy_d2d(dq, dst->data, src->data, ggml_nbytes(src), dst_stream)) GGML_ABORT("MI355X cpy_tensor_async: %s", qmm_last_error());
+    return true;
+}
+void backend_event_record(ggml_backend_t backend, ggml_backend_event_t event) {
+    auto * ctx = (mi355x_backend_ctx *) backend->context;
+    if (qmm_event_record(ctx->dev->qmm, (qmm_event *) event->context, qmm_stream(ctx->dev->qmm)))
+        GGML_ABORT("MI355X event_record: %s", qmm_last_error());
+}
+void backend_event_wait(ggml_backend_t backend, ggml_backend_event_t event) {
+    auto * ctx = (mi355x_backend_ctx *) backend->context;
+    if (qmm_stream_wait_event(ctx->dev->qmm, qmm_stream(ctx->dev->qmm), (qmm_event *) event->context))
+        GGML_ABORT("MI355X event_wait: %s", qmm_last_error());
 }
 
 void backend_synchronize(ggml_backend_t backend) {
@@ -473,17 +523,17 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
 const ggml_backend_i backend_iface = {
     /* .get_name           = */ backend_get_name,
     /* .free               = */ backend_free,
-    /* .set_tensor_async   = */ nullptr,
-    /* .get_tensor_async   = */ nullptr,
-    /* .cpy_tensor_async   = */ nullptr,
+    /* .set_tensor_async   = */ backend_set_tensor_async,
+    /* .get_tensor_async   = */ backend_get_tensor_async,
+    /* .cpy_tensor_async   = */ backend_cpy_tensor_async,
     /* .synchronize        = */ backend_synchronize,
     /* .graph_plan_create  = */ nullptr,
     /* .graph_plan_free    = */ nullptr,
     /* .graph_plan_update  = */ nullptr,
     /* .graph_plan_compute = */ nullptr,
     /* .graph_compute      = */ backend_graph_compute,
-    /* .event_record       = */ nullptr,
-    /* .event_wait         = */ nullptr,
+    /* .event_record       = */ backend_event_record,
+    /* .event_wait         = */ backend_event_wait,
 };
 
 ggml_guid_t backend_guid() {
@@ -504,13 +554,30 @@ void dev_get_props(ggml_backend_dev_t dev, struct ggml_backend_dev_props * props
     props->description = dev_get_description(dev);
     props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
     dev_get_memory(dev, &props->memory_free, &props->memory_total);
-    props->caps = { /* async */ false, /* host_buffer */ false, /* buffer_from_host_ptr */ false, /* events */ false };
+    props->caps = { /* async */ true, /* host_buffer */ false, /* buffer_from_host_ptr */ false, /* events */ true };
 }
 ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     auto * d = (mi355x_device_ctx *) dev->context;
     return new ggml_backend{ backend_guid(), backend_iface, dev, new mi355x_backend_ctx{ d, d->name } };
 }
 ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &((mi355x_device_ctx *) dev->context)->buft; }
+
+ggml_backend_event_t dev_event_new(ggml_backend_dev_t dev) {
+    qmm_event * e = qmm_event_create(((mi355x_device_ctx *) dev->context)->qmm);
+    if (!e) {
+        GGML_LOG_ERROR("MI355X event_new: %s\n", qmm_last_error());
+        return nullptr;
+    }
+    return new ggml_backend_event{ dev, e };
+}
+void dev_event_free(ggml_backend_dev_t dev, ggml_backend_event_t event) {
+    qmm_event_destroy(((mi355x_device_ctx *) dev->context)->qmm, (qmm_event *) event->context);
+    delete event;
+}
+void dev_event_synchronize(ggml_backend_dev_t dev, ggml_backend_event_t event) {
+    if (qmm_event_synchronize(((mi355x_device_ctx *) dev->context)->qmm, (qmm_event *) event->context))
+        GGML_ABORT("MI355X event_synchronize: %s", qmm_last_error());
+}
 
 bool dev_supports_op(ggml_backend_dev_t, const struct ggml_tensor * op) {
     switch (op->op) {
@@ -539,9 +606,9 @@ const ggml_backend_device_i device_iface = {
     /* .supports_op          = */ dev_supports_op,
     /* .supports_buft        = */ dev_supports_buft,
     /* .offload_op           = */ nullptr,
-    /* .event_new            = */ nullptr,
-    /* .event_free           = */ nullptr,
-    /* .event_synchronize    = */ nullptr,
+    /* .event_new            = */ dev_event_new,
+    /* .event_free           = */ dev_event_free,
+    /* .event_synchronize    = */ dev_event_synchronize,
 };
 
 // ----------------------------------------------------------------------------------------------- reg

@@ -214,6 +214,25 @@ int qmm_memcpy_d2d(qmm_ctx * c, void * dst, const void * src, size_t n, void * s
     HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->s(st)));
     return QMM_OK;
 }
+struct qmm_event { hipEvent_t ev; };
+int qmm_memcpy_h2d_async(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
+    if (!c) return fail(QMM_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->s(st)));
+    return QMM_OK;
+}
+int qmm_memcpy_d2h_async(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
+    if (!c) return fail(QMM_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->s(st)));
+    return QMM_OK;
+}
+int qmm_event_synchronize(qmm_ctx * c, qmm_event * e) {
+    if (!c || !e) return fail(QMM_EINVAL, "qmm_event_synchronize: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(e->ev));
+    return QMM_OK;
+}
 int qmm_memcpy2d_d2d(qmm_ctx * c, void * dst, size_t dpitch, const void * src, size_t spitch, size_t width, size_t height, void * st) {
     if (!c) return fail(QMM_EINVAL, "null ctx");
     if (width == 0 || height == 0) return QMM_OK;
@@ -222,7 +241,6 @@ int qmm_memcpy2d_d2d(qmm_ctx * c, void * dst, size_t dpitch, const void * src, s
     else HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, c->s(st)));
     return QMM_OK;
 }
-struct qmm_event { hipEvent_t ev; };
 qmm_event * qmm_event_create(qmm_ctx * c) {
     if (!c || hipSetDevice(c->device) != hipSuccess) { fail(QMM_EINVAL, "qmm_event_create: bad ctx"); return nullptr; }
     qmm_event * e = new qmm_event;

@@ -89,6 +89,10 @@ QMM_API void         qmm_free(qmm_ctx * ctx, void * dptr);
 QMM_API int          qmm_memcpy_h2d(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
 QMM_API int          qmm_memcpy_d2h(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
 QMM_API int          qmm_memcpy_d2d(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
+/* the same copies without the host-side wait: ordered on `stream` only (a pageable host buffer may still make the runtime
+ * stage or block; results are defined after qmm_synchronize or an event) */
+QMM_API int          qmm_memcpy_h2d_async(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
+QMM_API int          qmm_memcpy_d2h_async(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
 QMM_API int          qmm_memset(qmm_ctx * ctx, void * dst, int value, size_t bytes, void * stream);
 QMM_API int          qmm_synchronize(qmm_ctx * ctx, void * stream);
 
@@ -104,6 +108,7 @@ QMM_API qmm_event *  qmm_event_create(qmm_ctx * ctx);
 QMM_API void         qmm_event_destroy(qmm_ctx * ctx, qmm_event * ev);
 QMM_API int          qmm_event_record(qmm_ctx * ctx, qmm_event * ev, void * stream);
 QMM_API int          qmm_stream_wait_event(qmm_ctx * ctx, void * stream, qmm_event * ev);
+QMM_API int          qmm_event_synchronize(qmm_ctx * ctx, qmm_event * ev);              /* host waits for the event */
 
 QMM_API size_t       qmm_row_size(int type, int64_t k);
 

@@ -30,3 +30,16 @@ def test_row_split_matches_cpu_and_unsplit(n_virtual):
     assert not fails, "\n".join(fails[:20])
     m = re.search(r"(\d+) OK, (\d+) FAILED", out)
     assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) >= 200, out[-3000:]
+
+
+def test_async_transfers_and_events():
+    """set/get/cpy_tensor_async, event record / wait / synchronize and caps.async/events, driven through
+    ggml's public API across two logical devices (tests/cpp/test_async_events.cpp)"""
+    exe = ROOT / "oracle" / "_ref" / "test-async-events"
+    if not exe.exists() or not PLUGIN.exists():
+        pytest.skip("oracle/_ref/test-async-events or the plugin module is not built (needs the reference tree at build time)")
+    env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN), GGML_MI355X_VIRTUAL_DEVICES="2")
+    p = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=600, cwd=str(exe.parent))
+    out = p.stdout + p.stderr
+    m = re.search(r"(\d+) OK, (\d+) FAILED", out)
+    assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) >= 9, out[-3000:]
