@@ -346,3 +346,24 @@ def test_splitk_prefill_strided_dst_and_ragged_rows(qmm, oracle, t):
         assert (o[:, m:] == 7.0).all()
         assert np.array_equal(o, first)
         assert rel_l2(o[:, :m], oracle.mul_mat(t, w, k, x, ACT_REF)) < 1e-3
+
+
+@pytest.mark.parametrize("t", ALL, ids=IDS)
+def test_random_shapes_sweep_every_kernel(qmm, oracle, t):
+    """seeded random (M, K, N) draws: ragged row counts, K any multiple of the block size, and N on both sides of every
+    dispatch boundary (mat-vec <= 8 < few-token kernel <= 64/128 < tiled kernel, with and without split-K)"""
+    import ggml_hexagon_amd.synth as synth
+    rng = np.random.default_rng(1000 + t)
+    kblk = 32 if t in (Q4_0, Q8_0) else 256
+    n_choices = [1, 2, 7, 8, 9, 17, 31, 32, 33, 63, 64, 65, 100, 128, 129, 200, 257, 300]
+    for case in range(14):
+        m = int(rng.integers(1, 700))
+        k = kblk * int(rng.integers(1, 2304 // kblk + 1))
+        n = int(n_choices[int(rng.integers(0, len(n_choices)))])
+        w = synth.synth_weights(t, m, k, seed=case * 7 + t, sigma=0.25)
+        x = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+        got = qmm.mul_mat(t, dev(w), k, dev(x)).cpu().numpy()
+        want = oracle.mul_mat(t, w, k, x, ACT_REF)
+        assert got.shape == want.shape
+        err = rel_rms(got, want) if n <= 8 else rel_l2(got, want)
+        assert err < (2e-5 if n <= 8 else 1e-3), (TYPE_NAMES[t], m, k, n, err)
