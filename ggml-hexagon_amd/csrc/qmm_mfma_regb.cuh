@@ -387,7 +387,9 @@ mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const 
         if (NW >= 8 && wave >= NW / 2) run(std::false_type{});
         else                           run(std::true_type{});
     } else {
-        // Q6_K (eight fragments per K-step): the pipeline above does not fit the register file; unpack, then multiply
+        // Q6_K (eight fragments per K-step): the pipeline above does not fit the register file; unpack, then multiply.
+        // (Measured and dropped: walking Q6_K in 64-wide half K-steps through the pipelined branch, which the PERM 3
+        // activation order allows; the lane's 58 bytes are then requested once per half: 4096x14336x512 121 -> 163 us.)
         auto compute = [&](const Frags fr, const uint8_t * stage) {
 #pragma unroll
             for (int kk = 0; kk < NFRAG; ++kk) mfma_a(fr.f[kk], read_a(stage, 2 * kk + h));
