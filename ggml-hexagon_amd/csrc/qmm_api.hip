@@ -51,6 +51,30 @@ static int launch_matvec_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, c
     return QMM_OK;
 }
 
+template <int NTOK>
+static int launch_kmix_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K) {
+    const size_t lds = ((size_t) NTOK * K + (size_t) NTOK * (K / 256) * 4 + (size_t) NTOK * (K / 16) * 2 + 15) & ~(size_t) 15;
+    auto kern = matvec_kmix_kernel<NTOK>;
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    const int total = g.row_end[g.n - 1];
+    int nw = (total + c->cus - 1) / c->cus;
+    nw = nw > 8 ? 16 : nw > 4 ? 8 : 4;
+    int blocks = (total + nw - 1) / nw;
+    if (blocks > c->cus * c->mv_bpc) blocks = c->cus * c->mv_bpc;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * WAVE), lds, st, g, x, ldx, K, c->act_mode);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+static int launch_kmix(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K, int N) {
+    switch (N) {
+        case 1: return launch_kmix_n<1>(c, st, g, x, ldx, K);
+        case 2: return launch_kmix_n<2>(c, st, g, x, ldx, K);
+        case 3: return launch_kmix_n<3>(c, st, g, x, ldx, K);
+        case 4: return launch_kmix_n<4>(c, st, g, x, ldx, K);
+        default: return fail(QMM_EINVAL, "kmix matvec: N=%d", N);
+    }
+}
+
 template <int T>
 static int launch_matvec(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K, int N) {
     switch (N) {
@@ -133,6 +157,8 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->splitk = atoi(e);
     e = getenv("GGML_MI355X_ACT_MODE");
     if (e) c->act_mode = atoi(e) ? QMM_ACT_X86 : QMM_ACT_REF;
+    e = getenv("GGML_MI355X_MV_KMIX");
+    if (e) c->mv_kmix = atoi(e);
     e = getenv("GGML_MI355X_MV_BPC");
     if (e && atoi(e) >= 1 && atoi(e) <= 8) c->mv_bpc = atoi(e);
     e = getenv("GGML_MI355X_SKINNY");
@@ -339,6 +365,27 @@ int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, con
         int rc = check_mm(ws[i].type, ws[i].w, ws[i].w_row_bytes, K, x, ldx, "qmm_mul_mat");
         if (rc) return rc;
         if (ws[i].M < 0 || ws[i].ldd < ws[i].M) return fail(QMM_EINVAL, "qmm_mul_mat: ldd < M");
+    }
+    if (N <= 4 && nw >= 2 && nw <= MV_MAX_GROUP && c->mv_kmix) {
+        // K-quant matrices of different types share the Q8_K activations: one mixed-type launch for the whole group
+        bool kq = true, mixed = false;
+        for (int i = 0; i < nw; ++i) {
+            kq = kq && (ws[i].type == T_Q4_K || ws[i].type == T_Q5_K || ws[i].type == T_Q6_K) && ws[i].M > 0;
+            mixed = mixed || ws[i].type != ws[0].type;
+        }
+        if (kq && mixed && (size_t) N * K * 11 / 8 + 4096 <= 150 * 1024) {
+            MatvecGroup g;
+            memset(&g, 0, sizeof(g));
+            int rows = 0;
+            for (int i = 0; i < nw; ++i) {
+                g.w[i] = (const uint8_t *) ws[i].w;  g.dst[i] = ws[i].dst;  g.row_bytes[i] = ws[i].w_row_bytes;  g.ldd[i] = ws[i].ldd;
+                g.type[i] = ws[i].type;
+                rows += (int) ws[i].M;
+                g.row_end[i] = rows;
+            }
+            g.n = nw;
+            return launch_kmix(c, st, g, x, ldx, (int) K, (int) N);
+        }
     }
     if (N <= QMM_MATVEC_MAX_N) {
         // one launch per run of same-type weights (they share the in-kernel activation quantization)

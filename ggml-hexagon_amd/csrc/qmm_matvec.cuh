@@ -27,6 +27,7 @@ struct MatvecGroup {
     int64_t         ldd[MV_MAX_GROUP];
     int             row_end[MV_MAX_GROUP];   // cumulative row counts
     int             n;
+    int             type[MV_MAX_GROUP];      // per matrix; read by matvec_kmix_kernel only
 };
 
 template <int T> __host__ __device__ constexpr int act_block() { return Traits<T>::ACT == T_Q8_0 ? 32 : 256; }
@@ -100,6 +101,70 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
         }
         if (lane < NTOK) drow[(int64_t) lane * ldd] = out;
         if (row + W < total_rows) locate(row + W, wrow, drow, ldd);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-quant matrices of DIFFERENT types that share src1 (Q4_K_M's attn_q/attn_k in Q4_K beside attn_v in Q6_K, Q5_K_M's and the
+// 70B recipe's Q5_K/Q6_K mixes) in ONE launch: they all dot against the same Q8_K activations, so the staging is done once
+// (block sums per 16, which Q6_K needs and Q4_K/Q5_K add up in pairs; Q4_K's LDS order) and each wave picks the dot of the
+// matrix its row belongs to.  Saves the separate 3.4 MB launch (4.5 us at batch 1) of every such layer.
+template <int NTOK>
+__global__ void __launch_bounds__(1024)
+matvec_kmix_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t ldx, const int K, const int act_mode) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int8_t *  aq = reinterpret_cast<int8_t *>(smem);
+    float *   ad = reinterpret_cast<float *>(smem + (size_t) NTOK * K);
+    int16_t * ab = reinterpret_cast<int16_t *>(ad + (size_t) NTOK * (K / 256));
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE), nwaves = blockDim.x / WAVE;
+    const int units = K / 64;
+    const int iters = (units + WAVE - 1) / WAVE;
+    const int total_rows = g.row_end[g.n - 1];
+    const int W = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
+
+    quantize_rows<T_Q8_K, 16, T_Q4_K>(x, ldx, NTOK, K, act_mode, aq, ad, ab, tid, blockDim.x);
+    __syncthreads();
+
+    for (int row = gw; row < total_rows; row += W) {
+        int i = 0, b0 = 0;
+#pragma unroll
+        for (int k = 0; k < MV_MAX_GROUP - 1; ++k)
+            if (k < g.n - 1 && row >= g.row_end[k]) { i = k + 1; b0 = g.row_end[k]; }
+        const uint8_t * wrow = g.w[i] + (int64_t) (row - b0) * g.row_bytes[i];
+        float * drow = g.dst[i] + (row - b0);
+        const int64_t ldd = g.ldd[i];
+        const int type = __builtin_amdgcn_readfirstlane(g.type[i]);
+        float acc[NTOK];
+#pragma unroll
+        for (int n = 0; n < NTOK; ++n) acc[n] = 0.0f;
+        auto walk = [&](auto unit_tag, auto dot_fn) {
+            using U = decltype(unit_tag);
+            for (int it = 0; it < iters; ++it) {
+                const int u = lane + WAVE * it, uc = min(u, units - 1);
+                U un;
+                un.load(wrow, uc);
+#pragma unroll
+                for (int n = 0; n < NTOK; ++n) {
+                    const float p = dot_fn(un, uc, aq + (size_t) n * K, ad + (size_t) n * (K / 256), ab + (size_t) n * (K / 16));
+                    acc[n] += u < units ? p : 0.0f;
+                }
+            }
+        };
+        if (type == T_Q4_K)
+            walk(MvUnit<T_Q4_K>{}, [](const MvUnit<T_Q4_K> & un, int uc, const int8_t * a, const float * d, const int16_t * b) { return un.template dot<true>(uc, a, d, b); });
+        else if (type == T_Q5_K)
+            walk(MvUnit<T_Q5_K>{}, [](const MvUnit<T_Q5_K> & un, int uc, const int8_t * a, const float * d, const int16_t * b) { return un.template dot<true>(uc, a, d, b); });
+        else
+            walk(MvUnit<T_Q6_K>{}, [](const MvUnit<T_Q6_K> & un, int uc, const int8_t * a, const float * d, const int16_t * b) { return un.template dot<T_Q4_K>(uc, a, d, b); });
+        float out = 0.0f;
+#pragma unroll
+        for (int n = 0; n < NTOK; ++n) {
+            const float t = wave_sum(acc[n]);
+            if (lane == n) out = t;
+        }
+        if (lane < NTOK) drow[(int64_t) lane * ldd] = out;
     }
 }
 

@@ -47,7 +47,8 @@ template <> struct MvUnit<T_Q4_K> {
         q0  = ldg<uint4>(blk + 16 + 32 * (u & 3));
         q1  = ldg<uint4>(blk + 32 + 32 * (u & 3));
     }
-    // aq int8 [K]; ad f32 [K/256]; ab int16 [K/32] (sub-block sums)
+    // aq int8 [K]; ad f32 [K/256]; ab int16 [K/32] (sub-block sums; BS16: [K/16], sums of 16, as the mixed-type kernel stages them)
+    template <bool BS16 = false>
     __device__ __forceinline__ float dot(int u, const int8_t * aq, const float * ad, const int16_t * ab) const {
         const int b = u >> 2, j = u & 3;
         const int8_t * ap = aq + b * 256 + 64 * j;           // logical slot s sits at ((s + b) & 3): act_pos<12>
@@ -67,9 +68,18 @@ template <> struct MvUnit<T_Q4_K> {
         lo = dot4((int) (q1.w & m), a1.w, lo); hi = dot4((int) ((q1.w >> 4) & m), a3.w, hi);
         uint32_t sc, mn;
         k4_pair(hdr, j, sc, mn);
-        const uint32_t bs = *reinterpret_cast<const uint32_t *>(ab + b * 8 + 2 * j);
+        int bs_lo, bs_hi;                                    // sums of the activations under the low / high nibble sub-block
+        if (BS16) {
+            const uint2 b4 = *reinterpret_cast<const uint2 *>(ab + b * 16 + 4 * j);
+            bs_lo = (int) (int16_t) (b4.x & 0xffff) + ((int) b4.x >> 16);
+            bs_hi = (int) (int16_t) (b4.y & 0xffff) + ((int) b4.y >> 16);
+        } else {
+            const uint32_t bs = *reinterpret_cast<const uint32_t *>(ab + b * 8 + 2 * j);
+            bs_lo = (int) (int16_t) (bs & 0xffff);
+            bs_hi = (int) bs >> 16;
+        }
         const int isum = mul24((int) (sc & 0xff), lo) + mul24((int) (sc >> 8), hi);
-        const int msum = mul24((int) (mn & 0xff), (int) (int16_t) (bs & 0xffff)) + mul24((int) (mn >> 8), (int) bs >> 16);
+        const int msum = mul24((int) (mn & 0xff), bs_lo) + mul24((int) (mn >> 8), bs_hi);
         const float yd = ad[b];
         return (h2f(hdr.x & 0xffff) * yd) * (float) isum - (h2f(hdr.x >> 16) * yd) * (float) msum;
     }
@@ -86,6 +96,7 @@ template <> struct MvUnit<T_Q5_K> {
         q0  = ldg<uint4>(blk + 48 + 32 * (u & 3));
         q1  = ldg<uint4>(blk + 64 + 32 * (u & 3));
     }
+    template <bool BS16 = false>
     __device__ __forceinline__ float dot(int u, const int8_t * aq, const float * ad, const int16_t * ab) const {
         const int b = u >> 2, j = u & 3;
         const int8_t * ap = aq + b * 256 + 64 * j;           // logical slot s sits at ((s + b) & 3): act_pos<12>
@@ -104,9 +115,18 @@ template <> struct MvUnit<T_Q5_K> {
 #undef QMM_Q5
         uint32_t sc, mn;
         k4_pair(hdr, j, sc, mn);
-        const uint32_t bs = *reinterpret_cast<const uint32_t *>(ab + b * 8 + 2 * j);
+        int bs_lo, bs_hi;                                    // sums of the activations under the low / high nibble sub-block
+        if (BS16) {
+            const uint2 b4 = *reinterpret_cast<const uint2 *>(ab + b * 16 + 4 * j);
+            bs_lo = (int) (int16_t) (b4.x & 0xffff) + ((int) b4.x >> 16);
+            bs_hi = (int) (int16_t) (b4.y & 0xffff) + ((int) b4.y >> 16);
+        } else {
+            const uint32_t bs = *reinterpret_cast<const uint32_t *>(ab + b * 8 + 2 * j);
+            bs_lo = (int) (int16_t) (bs & 0xffff);
+            bs_hi = (int) bs >> 16;
+        }
         const int isum = mul24((int) (sc & 0xff), lo) + mul24((int) (sc >> 8), hi);
-        const int msum = mul24((int) (mn & 0xff), (int) (int16_t) (bs & 0xffff)) + mul24((int) (mn >> 8), (int) bs >> 16);
+        const int msum = mul24((int) (mn & 0xff), bs_lo) + mul24((int) (mn >> 8), bs_hi);
         const float yd = ad[b];
         return (h2f(hdr.x & 0xffff) * yd) * (float) isum - (h2f(hdr.x >> 16) * yd) * (float) msum;
     }
@@ -114,14 +134,15 @@ template <> struct MvUnit<T_Q5_K> {
 
 template <> struct MvUnit<T_Q6_K> : Unit<T_Q6_K> {
     static constexpr int W = 64, BSG = 16;
-    // ab int16 [K/16]
+    // ab int16 [K/16]; SWZ: the LDS order the activations were staged in (the mixed-type kernel stages Q4_K's)
+    template <int SWZ = T_Q6_K>
     __device__ __forceinline__ float dot(int u, const int8_t * aq, const float * ad, const int16_t * ab) const {
         const int b = u >> 2, n = (u >> 1) & 1, g = u & 1;
         const int k0 = b * 256 + 128 * n + 16 * g;
         int acc[4] = { 0, 0, 0, 0 };
         int4 a[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const int4 *>(aq + act_pos<T_Q6_K>(k0 + 32 * r));
+        for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const int4 *>(aq + act_pos<SWZ>(k0 + 32 * r));
         const uint32_t m4 = 0x0f0f0f0fu, m2 = 0x30303030u;
 #define QMM_Q6(i, A, B, H, c)                                                              \
         acc[0] = dot4((int) ((A & m4) | ((H << 4) & m2)), a[0].c, acc[0]);                  \

@@ -187,6 +187,23 @@ def test_group_launch_matches_single(qmm, maybe_ref):
             assert torch.equal(o, qmm.mul_mat(t, w, k, x))
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_mixed_type_group_one_launch(qmm, oracle, n):
+    """K-quant matrices of different types sharing src1 go out as ONE mixed-type mat-vec launch (matvec_kmix_kernel):
+    every matrix against the oracle, bit-identical to its own single launch, ragged row counts, K = 14336 included"""
+    import ggml_hexagon_amd.synth as synth
+    for k, spec in ((4096, ((Q4_K, 300), (Q4_K, 70), (Q6_K, 130))), (1024, ((Q5_K, 64), (Q6_K, 33), (Q4_K, 1), (Q5_K, 257))),
+                    (14336, ((Q6_K, 96), (Q4_K, 160)))):
+        ws_np = [(t, synth.synth_weights(t, m, k, seed=m + t, sigma=0.25)) for t, m in spec]
+        ws = [(t, dev(w)) for t, w in ws_np]
+        x = np.random.default_rng(k + n).uniform(-1, 1, (n, k)).astype(np.float32)
+        outs = [torch.full((n, w.shape[0]), 3.0, device="cuda") for _, w in ws]
+        qmm.mul_mat_group(ws, k, dev(x), outs)
+        for (t, w), (_, wd), o in zip(ws_np, ws, outs):
+            assert rel_rms(o.cpu().numpy(), oracle.mul_mat(t, w, k, x, ACT_REF)) < 2e-5, (TYPE_NAMES[t], k, n)
+            assert torch.equal(o, qmm.mul_mat(t, wd, k, dev(x)))
+
+
 # ----------------------------------------------------------------------------- MFMA path (N > 8)
 
 @pytest.mark.parametrize("t", ALL, ids=IDS)
