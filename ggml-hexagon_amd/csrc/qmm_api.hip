@@ -161,6 +161,8 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->mv_kmix = atoi(e);
     e = getenv("GGML_MI355X_MV_BPC");
     if (e && atoi(e) >= 1 && atoi(e) <= 8) c->mv_bpc = atoi(e);
+    e = getenv("GGML_MI355X_MM_GROUP");
+    if (e) c->mm_group = atoi(e);
     e = getenv("GGML_MI355X_SKINNY");
     if (e) c->skinny = atoi(e);
     e = getenv("GGML_MI355X_SKINNY_MAXN");
@@ -423,12 +425,19 @@ int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, con
         return QMM_OK;
     }
     int last_key = -1;                   // the group shares src1: its 16-bit operand is prepared once per activation format
-    for (int i = 0; i < nw; ++i) {
-        if (ws[i].M == 0) continue;
+    for (int i = 0; i < nw;) {
+        if (ws[i].M == 0) { ++i; continue; }
+        int j = i + 1;                   // run of same-type matrices: one tiled launch where the shapes allow (mfma_mul_mat_group)
+        while (j < nw && j - i < 4 && ws[j].type == ws[i].type && ws[j].M > 0) ++j;
         const int key = mfma_prep_key(c, ws[i].type, N, ws[i].M);
-        int rc = mfma_mul_mat(c, st, ws[i].type, ws[i].w, ws[i].w_row_bytes, K, ws[i].M, x, N, ldx, ws[i].dst, ws[i].ldd, key == last_key);
+        bool same_key = true;
+        for (int k = i + 1; k < j; ++k) same_key = same_key && mfma_prep_key(c, ws[k].type, N, ws[k].M) == key;
+        if (!same_key) j = i + 1;
+        int rc = j - i > 1 ? mfma_mul_mat_group(c, st, ws[i].type, ws + i, j - i, K, x, N, ldx, key == last_key)
+                           : mfma_mul_mat(c, st, ws[i].type, ws[i].w, ws[i].w_row_bytes, K, ws[i].M, x, N, ldx, ws[i].dst, ws[i].ldd, key == last_key);
         if (rc) return rc;
         last_key = key;
+        i = j;
     }
     return QMM_OK;
 }

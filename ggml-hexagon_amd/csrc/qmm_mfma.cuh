@@ -506,9 +506,10 @@ inline bool mfma_use_skinny(const qmm_ctx * c, int type, int64_t N, int64_t M, i
     if (!mfma_regb_supports(c, type) || !c->skinny) return false;
     return N <= c->skinny_max_n || (N <= c->skinny_max_n_few && (M + 31) / 32 * n_expert <= c->cus);
 }
+struct RegbMore;
 int  launch_mfma_regb(qmm_ctx * c, hipStream_t st, int type, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
                       const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
-                      float * dst, int64_t ldd, const int64_t * dst_off);
+                      float * dst, int64_t ldd, const int64_t * dst_off, const RegbMore * group = nullptr);
 
 inline int launch_mfma_any(qmm_ctx * c, hipStream_t st, int type, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
                            const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,

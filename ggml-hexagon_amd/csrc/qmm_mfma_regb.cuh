@@ -233,28 +233,49 @@ template <> struct Regb<T_Q6_K> {
 // stores, no flags); splitk_reduce_kernel then adds the ranges in order (deterministic), applies the per-token scale and
 // writes dst.  (An in-kernel combine by the last workgroup to arrive at a tile counter was measured first: with 128 KB
 // tiles its serial read of the other ranges cost more than the split gained; the extra launch is ~2 us and runs chip-wide.)
+// Matrices 2..4 of a group that shares src1 and the weight type (attn_q / attn_k / attn_v): one launch walks the row tiles of
+// all of them (the first matrix stays in the kernel's plain arguments).  tile_begin = first 256-row tile of the matrix in
+// blockIdx.x, col0 = its first column in the split-K partial slabs [range][token][mtot].
+struct RegbMore {
+    const uint8_t * w[3];
+    float *         dst[3];
+    int64_t         row_bytes[3];
+    int64_t         ldd[3];
+    int             m[3];
+    int             tile_begin[3];
+    int             col0[3];
+    int             n;            // how many of the three are used
+    int             mtot;         // rows of all matrices together (>= M of the first)
+};
+
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float * __restrict__ part, const int ksplit, const int N, const int M, const float * __restrict__ scale,
-                     float * __restrict__ dst, const int64_t ldd, const int vec) {
-    const int64_t range = (int64_t) N * M;
-    if (vec) {                                                 // M % 4 == 0, ldd % 4 == 0, dst 16-byte aligned
-        const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
-        if (i >= range) return;
+                     float * __restrict__ dst, const int64_t ldd, const int vec, const RegbMore more) {
+    const int mtot = more.n ? more.mtot : M;
+    const int64_t range = (int64_t) N * mtot;
+    const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * (vec ? 4 : 1);
+    if (i >= range) return;
+    const int t = (int) (i / mtot);
+    const int col = (int) (i - (int64_t) t * mtot);
+    float * out = dst;
+    int64_t ld = ldd;
+    int c0 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k < more.n && col >= more.col0[k]) { out = more.dst[k]; ld = more.ldd[k]; c0 = more.col0[k]; }
+    const int m = col - c0;
+    const float sc = scale[t];
+    if (vec) {                                                 // every M % 4 == 0, ldd % 4 == 0, dst 16-byte aligned
         float4 a = *reinterpret_cast<const float4 *>(part + i);
         for (int s = 1; s < ksplit; ++s) {
             const float4 b = *reinterpret_cast<const float4 *>(part + s * range + i);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
-        const int t = (int) (i / M), m = (int) (i - (int64_t) t * M);
-        const float sc = scale[t];
-        *reinterpret_cast<float4 *>(dst + t * ldd + m) = make_float4(a.x * sc, a.y * sc, a.z * sc, a.w * sc);
+        *reinterpret_cast<float4 *>(out + t * ld + m) = make_float4(a.x * sc, a.y * sc, a.z * sc, a.w * sc);
     } else {
-        const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-        if (i >= range) return;
         float a = part[i];
         for (int s = 1; s < ksplit; ++s) a += part[s * range + i];
-        const int t = (int) (i / M), m = (int) (i - (int64_t) t * M);
-        dst[t * ldd + m] = a * scale[t];
+        out[t * ld + m] = a * sc;
     }
 }
 
@@ -264,7 +285,7 @@ mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const 
                  const uint16_t * __restrict__ Xh, const int Kp, const float * __restrict__ scale,
                  const int * __restrict__ seg_start, const int * __restrict__ seg_count, const int N,
                  float * __restrict__ dst, const int64_t ldd, const int64_t * __restrict__ dst_off,
-                 const int ksplit, float * __restrict__ part) {
+                 const int ksplit, float * __restrict__ part, const RegbMore more) {
     using P = Regb<T>;
     constexpr int BK = P::BK, NFRAG = P::NFRAG, ROWB = BK * 2, SLOTS = BK / 8, NA = BN / 32;
     constexpr int NT = NW * 64;
@@ -280,9 +301,18 @@ mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const 
     const int segn = seg_count ? seg_count[expert] : N;
     const int tok0 = blockIdx.y * BN;
     if (tok0 >= segn) return;                                 // (never with ksplit > 1: plain MUL_MAT has no empty tiles)
-    const int row0 = blockIdx.x * (32 * NW) + wave * 32;
+    // which matrix of the group this row tile belongs to (wave-uniform)
+    const uint8_t * Wg = W;  float * dstg = dst;  int64_t rbg = row_bytes, lddg = ldd;  int Mg = M, col0 = 0, tile = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k < more.n && (int) blockIdx.x >= more.tile_begin[k]) {
+            Wg = more.w[k];  dstg = more.dst[k];  rbg = more.row_bytes[k];  lddg = more.ldd[k];  Mg = more.m[k];  col0 = more.col0[k];
+            tile = blockIdx.x - more.tile_begin[k];
+        }
+    const int mtot = more.n ? more.mtot : M;
+    const int row0 = tile * (32 * NW) + wave * 32;
     const int r = lane & 31, h = lane >> 5;
-    const uint8_t * wrow = W + (int64_t) expert * expert_bytes + (int64_t) min(row0 + r, M - 1) * row_bytes;
+    const uint8_t * wrow = Wg + (int64_t) expert * expert_bytes + (int64_t) min(row0 + r, Mg - 1) * rbg;
     const int nk = Kp / BK;                                   // even: Kp is a multiple of 128 (256 for the K-quants)
     const int per = ((nk + ksplit - 1) / ksplit + 1) & ~1;    // this workgroup's K-steps: [ks0, ks1), an even count
     const int ks0 = split * per, ks1 = min(ks0 + per, nk);
@@ -413,12 +443,12 @@ mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const 
     // A split-K range stores its unscaled tile to part[split][token][row] instead (splitk_reduce_kernel finishes the job).
     float *   sc_lds  = reinterpret_cast<float *>(lds);
     int64_t * off_lds = reinterpret_cast<int64_t *>(lds + 1024);
-    float *   out     = ksplit > 1 ? part + (int64_t) split * N * M : dst;
+    float *   out     = ksplit > 1 ? part + (int64_t) split * N * mtot + col0 : dstg;
     if (tid < BN) {
         const int t = tok0 + tid;
         const bool live = t < segn;
         sc_lds[tid]  = live ? (ksplit > 1 ? 1.0f : scale[seg0 + t]) : 0.0f;
-        off_lds[tid] = live ? (ksplit > 1 ? (int64_t) t * M : dst_off ? dst_off[seg0 + t] : (int64_t) t * ldd) : 0;
+        off_lds[tid] = live ? (ksplit > 1 ? (int64_t) t * mtot : dst_off ? dst_off[seg0 + t] : (int64_t) t * lddg) : 0;
     }
     __syncthreads();
     const int m = row0 + r;
@@ -427,7 +457,7 @@ mfma_regb_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, const 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int tl = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (tok0 + tl < segn && m < M) out[off_lds[tl] + m] = acc[i][e] * sc_lds[tl];
+            if (tok0 + tl < segn && m < Mg) out[off_lds[tl] + m] = acc[i][e] * sc_lds[tl];
         }
 }
 
@@ -473,7 +503,7 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
                      const uint16_t * __restrict__ Xh, const int Kp, const float * __restrict__ scale,
                      const int * __restrict__ seg_start, const int * __restrict__ seg_count, const int N,
                      float * __restrict__ dst, const int64_t ldd, const int64_t * __restrict__ dst_off,
-                     const int ksplit, float * __restrict__ part) {
+                     const int ksplit, float * __restrict__ part, const RegbMore more) {
     constexpr int BK = 64, ROWB = BK * 2, SLOTS = 8, NA = BN / 32;
     constexpr int NT = NW * 64;
     constexpr int X_CHUNKS = BN * SLOTS / NT;                 // 16-byte chunks of the activation tile per thread per K-step
@@ -487,9 +517,18 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
     const int segn = seg_count ? seg_count[expert] : N;
     const int tok0 = blockIdx.y * BN;
     if (tok0 >= segn) return;                                 // (never with ksplit > 1: plain MUL_MAT has no empty tiles)
-    const int row0 = blockIdx.x * (32 * NW) + wave * 32;
+    // which matrix of the group this row tile belongs to (wave-uniform)
+    const uint8_t * Wg = W;  float * dstg = dst;  int64_t rbg = row_bytes, lddg = ldd;  int Mg = M, col0 = 0, tile = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k < more.n && (int) blockIdx.x >= more.tile_begin[k]) {
+            Wg = more.w[k];  dstg = more.dst[k];  rbg = more.row_bytes[k];  lddg = more.ldd[k];  Mg = more.m[k];  col0 = more.col0[k];
+            tile = blockIdx.x - more.tile_begin[k];
+        }
+    const int mtot = more.n ? more.mtot : M;
+    const int row0 = tile * (32 * NW) + wave * 32;
     const int r = lane & 31, h = lane >> 5;
-    const uint8_t * wrow = W + (int64_t) expert * expert_bytes + (int64_t) min(row0 + r, M - 1) * row_bytes;
+    const uint8_t * wrow = Wg + (int64_t) expert * expert_bytes + (int64_t) min(row0 + r, Mg - 1) * rbg;
     const int nk = Kp / BK;                                   // K % 256 == 0 for Q4_K: nk is a multiple of 4
     const int nblk = K / 256;
     const int bper = (nblk + ksplit - 1) / ksplit;            // this workgroup's Q4_K blocks: [kb0, kb1)
@@ -618,12 +657,12 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
     // A split-K range stores its unscaled tile to part[split][token][row] instead (splitk_reduce_kernel finishes the job).
     float *   sc_lds  = reinterpret_cast<float *>(lds);
     int64_t * off_lds = reinterpret_cast<int64_t *>(lds + 1024);
-    float *   out     = ksplit > 1 ? part + (int64_t) split * N * M : dst;
+    float *   out     = ksplit > 1 ? part + (int64_t) split * N * mtot + col0 : dstg;
     if (tid < BN) {
         const int t = tok0 + tid;
         const bool live = t < segn;
         sc_lds[tid]  = live ? (ksplit > 1 ? 1.0f : scale[seg0 + t]) : 0.0f;
-        off_lds[tid] = live ? (ksplit > 1 ? (int64_t) t * M : dst_off ? dst_off[seg0 + t] : (int64_t) t * ldd) : 0;
+        off_lds[tid] = live ? (ksplit > 1 ? (int64_t) t * mtot : dst_off ? dst_off[seg0 + t] : (int64_t) t * lddg) : 0;
     }
     __syncthreads();
     const int m = row0 + r;
@@ -632,7 +671,7 @@ mfma_regb_q4k_kernel(const uint8_t * __restrict__ W, const int64_t row_bytes, co
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int tl = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (tok0 + tl < segn && m < M) out[off_lds[tl] + m] = acc[i][e] * sc_lds[tl];
+            if (tok0 + tl < segn && m < Mg) out[off_lds[tl] + m] = acc[i][e] * sc_lds[tl];
         }
 }
 
@@ -810,19 +849,24 @@ inline bool mfma_regb_supports(const qmm_ctx * c, int type) {
 template <int T>
 inline int launch_mfma_regb_t(qmm_ctx * c, hipStream_t st, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
                               const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
-                              float * dst, int64_t ldd, const int64_t * dst_off) {
+                              float * dst, int64_t ldd, const int64_t * dst_off, const RegbMore * group = nullptr) {
+    RegbMore more;
+    memset(&more, 0, sizeof(more));
+    if (group) more = *group;                                 // (callers group only where the 256-row tile is the choice)
+    const int tiles_x = more.n ? more.tile_begin[more.n - 1] + (more.m[more.n - 1] + 255) / 256 : (M + 255) / 256;
     // tile choice = chip fill: 256 rows x 128 tokens (8 waves, two per SIMD) when that gives (almost) every CU a workgroup,
     // else 128 x 128, else 128 x 64 / 128 x 32 (the weight unpack is then repeated 2x / 4x, on CUs that would otherwise idle).
     // n_tiles_y counts 128-token tiles of the (worst-case) token range.
     const int ksplit = n_expert == 1 ? op.ksplit : 1;
-    const int64_t wg_256 = (int64_t) ((M + 255) / 256) * n_tiles_y * n_expert;
+    const int64_t wg_256 = (int64_t) tiles_x * n_tiles_y * n_expert;
     const int64_t wg_128 = (int64_t) ((M + 127) / 128) * n_tiles_y * n_expert;
 #define QMM_REGB(NWv, BNv, ROWS, TY)                                                                                                   \
     do {                                                                                                                               \
         auto kern = T == T_Q4_K ? mfma_regb_q4k_kernel<NWv, BNv> : mfma_regb_kernel<T, NWv, BNv>;                                      \
         const size_t lds = (size_t) 2 * BNv * Regb<T>::BK * 2 < 2048 ? 2048 : (size_t) 2 * BNv * Regb<T>::BK * 2;                     \
-        hipLaunchKernelGGL(kern, dim3((M + ROWS - 1) / ROWS, TY, n_expert * ksplit), dim3(NWv * 64), lds, st, (const uint8_t *) W,     \
-                           rb, eb, M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off, ksplit, op.part);         \
+        hipLaunchKernelGGL(kern, dim3(more.n ? tiles_x : (M + ROWS - 1) / ROWS, TY, n_expert * ksplit), dim3(NWv * 64), lds, st,       \
+                           (const uint8_t *) W, rb, eb, M, K, op.xh, op.Kp, op.scale, seg_start, seg_count, N, dst, ldd, dst_off,      \
+                           ksplit, op.part, more);                                                                                     \
     } while (0)
 #define QMM_SKINNY(NWSv, NAv)                                                                                                          \
     hipLaunchKernelGGL((mfma_skinny_kernel<T, NWSv, NAv>), dim3((M + 31) / 32, (N + 32 * NAv - 1) / (32 * NAv), n_expert),             \
@@ -830,17 +874,19 @@ inline int launch_mfma_regb_t(qmm_ctx * c, hipStream_t st, const void * W, int64
                        dst, ldd, dst_off)
     if (op.frag_major && N <= 32) QMM_SKINNY(8, 1);           // (16 waves per group measured no better, Q6_K worse)
     else if (op.frag_major)       QMM_SKINNY(8, 2);
-    else if (ksplit > 1 || wg_256 * 10 >= (int64_t) c->cus * 8) QMM_REGB(8, 128, 256, n_tiles_y);
+    else if (more.n || ksplit > 1 || wg_256 * 10 >= (int64_t) c->cus * 8) QMM_REGB(8, 128, 256, n_tiles_y);
     else if (wg_128 >= c->cus && T != T_Q6_K) QMM_REGB(4, 128, 128, n_tiles_y);   // (Q6_K: this shape spills, 4.5x slower)
     else if (2 * wg_128 >= c->cus / 2)       QMM_REGB(4, 64, 128, 2 * n_tiles_y);
     else                                     QMM_REGB(4, 32, 128, 4 * n_tiles_y);
 #undef QMM_REGB
 #undef QMM_SKINNY
     if (ksplit > 1 && !op.frag_major) {
-        const int vec = M % 4 == 0 && ldd % 4 == 0 && ((uintptr_t) dst & 15) == 0;
-        const int64_t items = ((int64_t) N * M + (vec ? 3 : 0)) / (vec ? 4 : 1);
+        int vec = M % 4 == 0 && ldd % 4 == 0 && ((uintptr_t) dst & 15) == 0;
+        for (int k = 0; k < more.n; ++k) vec = vec && more.m[k] % 4 == 0 && more.ldd[k] % 4 == 0 && ((uintptr_t) more.dst[k] & 15) == 0;
+        const int mtot = more.n ? more.mtot : M;
+        const int64_t items = ((int64_t) N * mtot + (vec ? 3 : 0)) / (vec ? 4 : 1);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned) ((items + 255) / 256)), dim3(256), 0, st, op.part, ksplit, N, M,
-                           op.scale, dst, ldd, vec);
+                           op.scale, dst, ldd, vec, more);
     }
     HIP_TRY(hipGetLastError());
     return QMM_OK;
@@ -848,14 +894,71 @@ inline int launch_mfma_regb_t(qmm_ctx * c, hipStream_t st, const void * W, int64
 
 inline int launch_mfma_regb(qmm_ctx * c, hipStream_t st, int type, const void * W, int64_t rb, int64_t eb, int n_expert, int M, int K,
                             const MfmaOperand & op, const int * seg_start, const int * seg_count, int N, int n_tiles_y,
-                            float * dst, int64_t ldd, const int64_t * dst_off) {
+                            float * dst, int64_t ldd, const int64_t * dst_off, const RegbMore * group) {
     switch (type) {
-        case T_Q4_K: return launch_mfma_regb_t<T_Q4_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
-        case T_Q5_K: return launch_mfma_regb_t<T_Q5_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
-        case T_Q8_0: return launch_mfma_regb_t<T_Q8_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
-        case T_Q6_K: return launch_mfma_regb_t<T_Q6_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
-        default:     return launch_mfma_regb_t<T_Q4_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off);
+        case T_Q4_K: return launch_mfma_regb_t<T_Q4_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off, group);
+        case T_Q5_K: return launch_mfma_regb_t<T_Q5_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off, group);
+        case T_Q8_0: return launch_mfma_regb_t<T_Q8_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off, group);
+        case T_Q6_K: return launch_mfma_regb_t<T_Q6_K>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off, group);
+        default:     return launch_mfma_regb_t<T_Q4_0>(c, st, W, rb, eb, n_expert, M, K, op, seg_start, seg_count, N, n_tiles_y, dst, ldd, dst_off, group);
     }
+}
+
+// Plain MUL_MATs that share src1 and the weight type (attn_q / attn_k / attn_v at prefill): one launch of the tiled kernel
+// over the row tiles of all of them and one reduce, instead of a launch (and, with split-K, a reduce) per matrix; the 1024-row
+// matrices alone are 16 tiles each.  Falls back to one call per matrix where the few-token kernel or a smaller tile applies.
+inline int mfma_mul_mat_group(qmm_ctx * c, hipStream_t st, int type, const qmm_weight * ws, int n, int64_t K, const float * x, int64_t N,
+                              int64_t ldx, bool reuse_prep) {
+    int64_t mtot = 0, tiles = 0;
+    for (int i = 0; i < n; ++i) { mtot += ws[i].M; tiles += (ws[i].M + 255) / 256; }
+    tiles *= (N + 127) / 128;
+    int ksplit = 1;
+    if (c->splitk && tiles * 10 < (int64_t) c->cus * 8) {
+        int64_t s = c->cus / tiles;
+        if (s > 8) s = 8;
+        if (c->splitk > 1 && s > c->splitk) s = c->splitk;
+        if (s > K / 512) s = K / 512;
+        ksplit = s < 2 ? 1 : (int) s;
+    }
+    const bool ok = n >= 2 && n <= 4 && c->mm_group && mfma_regb_supports(c, type) && N > c->skinny_max_n_few &&
+                    (ksplit > 1 || tiles * 10 >= (int64_t) c->cus * 8);
+    if (!ok) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = mfma_mul_mat(c, st, type, ws[i].w, ws[i].w_row_bytes, K, ws[i].M, x, N, ldx, ws[i].dst, ws[i].ldd, reuse_prep || i > 0);
+            if (rc) return rc;
+        }
+        return QMM_OK;
+    }
+    const int Kp = mfma_kpad(K), Np = mfma_npad(N);
+    const size_t xh_bytes = (size_t) Np * Kp * 2;
+    const size_t sc_bytes = ((size_t) Np * 4 + 255) & ~(size_t) 255;
+    const size_t need = xh_bytes + sc_bytes + (ksplit > 1 ? (size_t) ksplit * N * mtot * sizeof(float) : 0) + 256;
+    int rc = ensure_ws(c, need);
+    if (rc) return rc;
+    uint16_t * xh = (uint16_t *) c->ws;
+    float * scale = (float *) ((uint8_t *) c->ws + xh_bytes);
+    if (!reuse_prep) {
+        const bool q8_0 = (type == T_Q4_0 || type == T_Q8_0);
+        rc = q8_0 ? launch_prep<T_Q8_0>(c, st, type, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, 0, xh, scale)
+                  : launch_prep<T_Q8_K>(c, st, type, x, ldx, nullptr, nullptr, (int) N, Np, (int) K, Kp, 0, xh, scale);
+        if (rc) return rc;
+    }
+    MfmaOperand op = { xh, scale, Kp, 0 };
+    op.ksplit = ksplit;
+    op.part = reinterpret_cast<float *>((uint8_t *) c->ws + xh_bytes + sc_bytes);
+    RegbMore more;
+    memset(&more, 0, sizeof(more));
+    int tile = (int) ((ws[0].M + 255) / 256), col = (int) ws[0].M;
+    for (int i = 1; i < n; ++i) {
+        more.w[i - 1] = (const uint8_t *) ws[i].w;  more.dst[i - 1] = ws[i].dst;  more.row_bytes[i - 1] = ws[i].w_row_bytes;
+        more.ldd[i - 1] = ws[i].ldd;  more.m[i - 1] = (int) ws[i].M;  more.tile_begin[i - 1] = tile;  more.col0[i - 1] = col;
+        tile += (int) ((ws[i].M + 255) / 256);
+        col += (int) ws[i].M;
+    }
+    more.n = n - 1;
+    more.mtot = (int) mtot;
+    return launch_mfma_regb(c, st, type, ws[0].w, ws[0].w_row_bytes, 0, 1, (int) ws[0].M, (int) K, op, nullptr, nullptr, (int) N, Np / 128,
+                            ws[0].dst, ws[0].ldd, nullptr, &more);
 }
 
 } // namespace qmm

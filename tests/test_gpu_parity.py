@@ -204,6 +204,25 @@ def test_mixed_type_group_one_launch(qmm, oracle, n):
             assert torch.equal(o, qmm.mul_mat(t, wd, k, dev(x)))
 
 
+@pytest.mark.parametrize("t", ALL, ids=IDS)
+def test_prefill_group_one_tiled_launch(qmm, oracle, t):
+    """same-type matrices sharing src1 at prefill batch sizes go out as ONE tiled launch (+ one split-K reduce): every
+    matrix against the oracle and identical to its own single launch; ragged row counts, strided dst, 2 to 4 matrices"""
+    import ggml_hexagon_amd.synth as synth
+    kblk = 32 if t in (Q4_0, Q8_0) else 256
+    for k, ms, n in ((kblk * (2048 // kblk), (512, 128, 128), 300), (kblk * (1024 // kblk), (300, 70), 200), (kblk * (1536 // kblk), (256, 256, 1, 33), 512)):
+        ws_np = [synth.synth_weights(t, m, k, seed=m + i, sigma=0.25) for i, m in enumerate(ms)]
+        ws = [(t, dev(w)) for w in ws_np]
+        x = np.random.default_rng(k + n).uniform(-1, 1, (n, k)).astype(np.float32)
+        big = [torch.full((n, m + 8), 3.0, device="cuda") for m in ms]
+        outs = [b[:, :m] for b, m in zip(big, ms)]
+        qmm.mul_mat_group(ws, k, dev(x), outs)
+        for w, (_, wd), o, b, m in zip(ws_np, ws, outs, big, ms):
+            assert (b[:, m:] == 3.0).all()
+            assert rel_l2(o.cpu().numpy(), oracle.mul_mat(t, w, k, x, ACT_REF)) < 1e-3, (TYPE_NAMES[t], k, m, n)
+            assert torch.equal(o, qmm.mul_mat(t, wd, k, dev(x)))
+
+
 # ----------------------------------------------------------------------------- MFMA path (N > 8)
 
 @pytest.mark.parametrize("t", ALL, ids=IDS)
