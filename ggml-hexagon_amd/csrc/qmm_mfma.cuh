@@ -2,25 +2,27 @@
 //
 //   dst[n, m] = sum_k W[m, k] * x[n, k]        N > 8 tokens
 //
-// Two launches per MUL_MAT:
-//   1. prep_act_kernel  f32 activations -> 16-bit MFMA operand rows  Xh[Npad][Kp]  (+ one f32 scale per token)
-//        QMM_PREC_F16_Q8 : the row is quantized to Q8_0 / Q8_K exactly as the CPU backend does
+// This file: the activation side and the host logic shared by all prefill kernels, plus the LDS-tile kernel.
+//   prep_act_kernel  f32 activations -> 16-bit MFMA operand  Xh[Npad][Kp]  (+ one f32 scale per token), once per src1
+//        QMM_PREC_F16_Q8 (default): the row is quantized to Q8_0 / Q8_K exactly as the CPU backend does
 //                          (ggml-cpu.c:6807-6842), then each value q*d is stored as f16 relative to the
 //                          row's largest block scale (|value| <= 127, no f16 range problem); the GEMM
 //                          therefore multiplies the SAME quantized activations as ggml's vec_dot, and the
 //                          only difference left is f16 rounding of the operands (~2^-12 relative).
+//                          The row is written in the k-order (PERM) and layout (row-major / fragment-major)
+//                          the weight kernel's lane ownership wants.
 //        QMM_PREC_BF16   : plain round-to-nearest bf16 of x (no Q8 emulation).
-//   2. mfma_kernel      each workgroup owns a BN-token x BM-row tile of dst.  Per K-step it
+//   weight kernels, QMM_PREC_F16_Q8: qmm_mfma_regb.cuh (register-B tiled kernels, few-token kernel, split-K, groups).
+//   mfma_kernel (here), QMM_PREC_BF16 only: each workgroup owns a BN-token x BM-row tile of dst.  Per K-step it
 //        - fetches one weight *unit* per thread straight from HBM (16-byte loads, qmm_device.cuh),
-//          unpacks it bit-exactly to f32 (Unit<T>::to_f32), rounds to f16/bf16 and stores it into the
-//          XOR-swizzled LDS tile Ws[BM][BK];
+//          unpacks it bit-exactly to f32 (Unit<T>::to_f32), rounds to bf16 and stores it into the
+//          XOR-swizzled LDS tile Ws[BM][BK] (4 producer waves);
 //        - copies the matching Xh tile into Xs[BN][BK];
-//        - runs v_mfma_f32_32x32x16_{f16,bf16} with tokens on the MFMA row index and weight rows on
-//          the column (= lane) index, so that the epilogue writes 128 contiguous bytes of dst per
+//        - runs v_mfma_f32_32x32x16_bf16 (4 consumer waves) with tokens on the MFMA row index and weight
+//          rows on the column (= lane) index, so that the epilogue writes 128 contiguous bytes of dst per
 //          half-wave.
-//      Global loads for K-step s+1 are issued before the MFMAs of step s (register prefetch).
 //
-// MoE (MUL_MAT_ID) reuses the kernel: blockIdx.z selects the expert, seg_start/seg_count (device
+// MoE (MUL_MAT_ID) reuses the kernels: blockIdx.z selects the expert, seg_start/seg_count (device
 // arrays) give the expert's slice of the expert-sorted token list, dst_off scatters the rows.
 #pragma once
 
