@@ -33,21 +33,23 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def roofline_leg(hp, q, n_tokens, torch):
+def roofline_leg(hp, q, n_batch, torch, n_outputs=None):
     """HIP-event timing of the pass's launches, bucketed by kernel.  The model's 32 layers give every launch shape 16-32
     distinct weight sets, so each bucket is issued back to back on rotating weights (no Infinity-Cache reuse) inside ONE
     event pair on the launch stream, behind a spin kernel that keeps the host ahead of the GPU.  Average launch duration
     = bucket time / launches (it includes the kernel-to-kernel boundary, not a per-launch event cost)."""
-    x, dst_local, _, ids = hp.prepare(n_tokens)
     buckets = {}
     for grp in hp.wl.groups:
+        n_tokens = hp.wl.group_tokens(grp, n_batch, n_outputs)          # the groups computed on the output rows only run at n_outputs
+        x, dst_local, _, ids = hp.prepare(n_tokens)
         m0 = grp.mats[0]
         if m0.n_expert:
             for m in grp.mats:
                 ne11 = m.n_used if m.name.endswith("down_exps") else 1
                 w, _ = hp.weights[m.name]
-                fn = (lambda m=m, w=w, ne11=ne11: q.mul_mat_id(m.type, w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=dst_local[("id", m.M)]))
-                buckets.setdefault(("id", m.type), []).append((fn, m.algo_bytes(n_tokens), m.flops(n_tokens)))
+                fn = (lambda m=m, w=w, ne11=ne11, x=x, ids=ids, dst_local=dst_local:
+                      q.mul_mat_id(m.type, w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=dst_local[("id", m.M)]))
+                buckets.setdefault(("id", m.type, n_tokens > 8), []).append((fn, m.algo_bytes(n_tokens), m.flops(n_tokens)))
             continue
         # one launch per run of same-type weights inside the group (that is how qmm_mul_mat_group issues them)
         i = 0
@@ -64,8 +66,8 @@ def roofline_leg(hp, q, n_tokens, torch):
                 outs.append(dst_local[(m.name.split(".")[-1], w.shape[0])])
                 nbytes += w.numel() + n_tokens * w.shape[0] * 4
                 fl += 2 * w.shape[0] * m.K * n_tokens
-            fn = (lambda ws=ws, outs=outs, K=m0.K: q.mul_mat_group(ws, K, x[K], outs))
-            buckets.setdefault(("mm", grp.mats[i].type), []).append((fn, nbytes, fl))
+            fn = (lambda ws=ws, outs=outs, K=m0.K, x=x: q.mul_mat_group(ws, K, x[K], outs))
+            buckets.setdefault(("mm", grp.mats[i].type, n_tokens > 8), []).append((fn, nbytes, fl))
             i = j
     torch.cuda.synchronize()
     torch.cuda._sleep(int(2.0e8))
@@ -97,10 +99,14 @@ def cpu_baseline(wl, cores):
     orc = None if ref else Oracle()
     mats = [m for m in wl.all_mats() if not m.n_expert]
     per_layer = (len(mats) - 1) // wl.n_layer
-    shapes = {}
-    for m in mats:
-        shapes.setdefault((m.type, m.K, m.M), 0)
-        shapes[(m.type, m.K, m.M)] += 1
+    shapes, shapes_out = {}, {}           # (type, K, M) -> count; of which in groups a prompt batch runs at n_outputs = 1
+    for g in wl.groups:
+        for m in g.mats:
+            if m.n_expert:
+                continue
+            shapes[(m.type, m.K, m.M)] = shapes.get((m.type, m.K, m.M), 0) + 1
+            if g.outputs_only:
+                shapes_out[(m.type, m.K, m.M)] = shapes_out.get((m.type, m.K, m.M), 0) + 1
     t_tg, t_pp, spent = 0.0, 0.0, time.perf_counter()
     rng = np.random.default_rng(0)
     for (t, K, M), count in shapes.items():
@@ -112,6 +118,11 @@ def cpu_baseline(wl, cores):
         else:
             t0 = time.perf_counter(); orc.mul_mat(t, w, K, x1); dt = time.perf_counter() - t0
         t_tg += dt * (M / Ms) * count
+        n_out = shapes_out.get((t, K, M), 0)                  # these run at N = 1 in the prompt pass too
+        t_pp += dt * (M / Ms) * n_out
+        count -= n_out
+        if count == 0:
+            continue
         if time.perf_counter() - spent < 25.0:
             xp = rng.uniform(-1, 1, (512, K)).astype(np.float32)
             Mp = min(Ms, 4096)
@@ -125,7 +136,8 @@ def cpu_baseline(wl, cores):
     return {"value": round(1.0 / t_tg, 3), "unit": "tok/s (tg128)", "pp512_tok_s": None if t_pp != t_pp else round(512.0 / t_pp, 2),
             "cores": cores, "kind": kind, "variant": getattr(ref, "variant", "scalar+omp"),
             "sample": f"each distinct (type,K,M) of {wl.name} once at N=1 (x3) and N=512 (rows capped at 16384/4096, scaled), "
-                      f"summed over the model's {len(mats)} MUL_MATs; {per_layer} per layer"}
+                      f"summed over the model's {len(mats)} MUL_MATs ({per_layer} per layer); prompt pass as llama-bench runs it: "
+                      f"last layer's FFN and the output projection at n_outputs = 1"}
 
 
 def main():
@@ -138,6 +150,8 @@ def main():
     ap.add_argument("--n-gen", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--all-logits", action="store_true",
+                    help="prompt pass with logits for every token (n_outputs = n_prompt) instead of llama-bench's last-token-only")
     args = ap.parse_args()
 
     import torch
@@ -169,6 +183,10 @@ def main():
     hp = HotPath(q, wl, dev, rank, world, concat)
     hp.prepare(args.n_prompt)
     hp.prepare(1)
+    # llama-bench's prompt test wants the last token's logits only (llama_batch_get_one: batch.logits = NULL ->
+    # n_outputs_all = 1, src/llama-context.cpp:1232-1244): the last layer's FFN and the output projection then run on
+    # one row (ggml_get_rows(cur, inp_out_ids), src/llama-model.cpp:4270-4275)
+    n_out_pp = None if args.all_logits else 1
     use_graph = world == 1 and not args.no_graph
     graph = hp.capture(1) if use_graph else None
 
@@ -181,7 +199,7 @@ def main():
 
     def step(e=None):
         if e: e[0].record()
-        hp.run(args.n_prompt)
+        hp.run(args.n_prompt, n_out_pp)
         if e: e[1].record()
         for _ in range(args.n_gen):
             if graph is not None:
@@ -211,15 +229,16 @@ def main():
 
     # ---- roofline leg: per-launch HIP events (this rank's shard of the work)
     agg1 = roofline_leg(hp, q, 1, torch)
-    aggp = roofline_leg(hp, q, args.n_prompt, torch)
+    aggp = roofline_leg(hp, q, args.n_prompt, torch, n_out_pp)
 
-    def dominant(agg):
-        key = max(agg, key=lambda k: agg[k][2])
+    def dominant(agg, batched=None):
+        keys = [k for k in agg if batched is None or k[2] == batched]
+        key = max(keys, key=lambda k: agg[k][2])
         nb, fl, sec, cnt = agg[key]
         return key, nb, fl, sec, cnt
 
     k1, nb1, fl1, s1, c1 = dominant(agg1)
-    kp, nbp, flp, sp, cp = dominant(aggp)
+    kp, nbp, flp, sp, cp = dominant(aggp, batched=True)
     traffic = None
     tf = ROOT / "profiles" / "pmc_traffic.json"
     if tf.exists():
@@ -243,13 +262,15 @@ def main():
         "vs_baseline": None, "dtype": "int8 dot (tg) / f16 MFMA on Q8-quantized activations (pp), f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{wl.name}: {len(wl.all_mats())} MUL_MATs/pass, {wl.weight_bytes() / 1e9:.2f} GB quantized weights, "
-                               f"pp{args.n_prompt} + tg{args.n_gen} per step", "n_prompt": args.n_prompt, "n_gen": args.n_gen,
+                               f"pp{args.n_prompt} + tg{args.n_gen} per step; prompt pass with "
+                               + ("logits for every token" if args.all_logits else "n_outputs = 1 as llama-bench runs it (last layer's FFN and the output projection on one row)"),
+                   "n_prompt": args.n_prompt, "n_gen": args.n_gen, "n_outputs_pp": args.n_prompt if args.all_logits else 1,
                    "parallelism": "single GPU" if world == 1 else f"ggml row split over {world} GPUs, RCCL all-gather concat",
                    "tg_launch": "hipGraph replay" if graph is not None else "eager"},
         "tg128_tok_s": round(tg_tok_s, 2), "pp512_tok_s": round(pp_tok_s, 2),
         "tg_ms_per_token": round(tg_s / args.n_gen * 1e3, 4), "pp_ms_per_batch": round(pp_s * 1e3, 3),
         "tg_algo_GBs": round(wl.algo_bytes(1) / world / (tg_s / args.n_gen) / 1e9, 1),
-        "pp_algo_TFLOPs": round(wl.flops(args.n_prompt) / world / pp_s / 1e12, 1),
+        "pp_algo_TFLOPs": round(wl.flops(args.n_prompt, n_out_pp) / world / pp_s / 1e12, 1),
         "roofline": roof, "roofline_pp": roof_pp,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

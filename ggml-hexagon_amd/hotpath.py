@@ -72,11 +72,15 @@ class HotPath:
         self.io[n_tokens] = (x, dst_local, dst_full, ids)
         return self.io[n_tokens]
 
-    def run(self, n_tokens: int):
-        """issue the whole pass on the current stream (asynchronous)"""
-        x, dst_local, dst_full, ids = self.prepare(n_tokens)
+    def run(self, n_tokens: int, n_outputs=None):
+        """issue the whole pass on the current stream (asynchronous).  n_outputs: how many of the batch's tokens want
+        logits; the groups llama.cpp computes on the output rows only (workload.Group.outputs_only) run at that size
+        (llama-bench's prompt test: 1).  None = every token (token generation: n_tokens = 1 anyway)."""
+        io_all = self.prepare(n_tokens)
+        io_out = io_all if n_outputs is None or n_outputs >= n_tokens else self.prepare(n_outputs)
         q = self.q
         for grp in self.wl.groups:
+            x, dst_local, dst_full, ids = io_out if grp.outputs_only else io_all
             m0 = grp.mats[0]
             if m0.n_expert:
                 for m in grp.mats:

@@ -40,8 +40,13 @@ class MatMul:
 
 @dataclass
 class Group:
-    """MUL_MATs that share src1 (issued as one grouped launch when batch <= 8)"""
+    """MUL_MATs that share src1 (issued as one grouped launch).  outputs_only: in a prompt batch llama.cpp computes this
+    group on the rows whose logits are wanted only: after the last layer's attention `cur` is cut down to the output rows
+    (`ggml_get_rows(cur, inp_out_ids)`, src/llama-model.cpp:4270-4275), so the last layer's FFN and the output projection
+    see n_outputs tokens; llama-bench's prompt test asks for the last token's logits only (llama_batch_get_one leaves
+    batch.logits NULL -> n_outputs_all = 1, src/llama-context.cpp:1232-1244)."""
     mats: list
+    outputs_only: bool = False
 
 
 @dataclass
@@ -57,11 +62,14 @@ class Workload:
     def weight_bytes(self) -> int:
         return sum(m.weight_bytes for m in self.all_mats())
 
-    def algo_bytes(self, n_tokens: int) -> int:
-        return sum(m.algo_bytes(n_tokens) for m in self.all_mats())
+    def group_tokens(self, g: Group, n_tokens: int, n_outputs=None) -> int:
+        return n_tokens if n_outputs is None or not g.outputs_only else min(n_tokens, n_outputs)
 
-    def flops(self, n_tokens: int) -> int:
-        return sum(m.flops(n_tokens) for m in self.all_mats())
+    def algo_bytes(self, n_tokens: int, n_outputs=None) -> int:
+        return sum(m.algo_bytes(self.group_tokens(g, n_tokens, n_outputs)) for g in self.groups for m in g.mats)
+
+    def flops(self, n_tokens: int, n_outputs=None) -> int:
+        return sum(m.flops(self.group_tokens(g, n_tokens, n_outputs)) for g in self.groups for m in g.mats)
 
 
 def use_more_bits(i: int, n: int) -> bool:      # src/llama-quant.cpp:129-131
@@ -88,15 +96,16 @@ def _llama(name, n_layer, n_embd, n_ff, n_head, n_head_kv, n_vocab, recipe, n_ex
         w.groups.append(Group([MatMul(f"blk.{i}.attn_q", tq, n_embd, n_embd), MatMul(f"blk.{i}.attn_k", tk, n_embd, kv),
                                MatMul(f"blk.{i}.attn_v", tv, n_embd, kv)]))
         w.groups.append(Group([MatMul(f"blk.{i}.attn_output", to, n_embd, n_embd)]))
+        last = i == n_layer - 1                      # its FFN runs on the output rows only in a prompt batch (Group docstring)
         if n_expert:
-            w.groups.append(Group([MatMul(f"blk.{i}.ffn_gate_exps", tg, n_embd, n_ff, n_expert, n_used)]))
-            w.groups.append(Group([MatMul(f"blk.{i}.ffn_up_exps", tg, n_embd, n_ff, n_expert, n_used)]))
-            w.groups.append(Group([MatMul(f"blk.{i}.ffn_down_exps", td, n_ff, n_embd, n_expert, n_used)]))
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_gate_exps", tg, n_embd, n_ff, n_expert, n_used)], last))
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_up_exps", tg, n_embd, n_ff, n_expert, n_used)], last))
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_down_exps", td, n_ff, n_embd, n_expert, n_used)], last))
         else:
-            w.groups.append(Group([MatMul(f"blk.{i}.ffn_gate", tg, n_embd, n_ff), MatMul(f"blk.{i}.ffn_up", tg, n_embd, n_ff)]))
-            w.groups.append(Group([MatMul(f"blk.{i}.ffn_down", td, n_ff, n_embd)]))
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_gate", tg, n_embd, n_ff), MatMul(f"blk.{i}.ffn_up", tg, n_embd, n_ff)], last))
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_down", td, n_ff, n_embd)], last))
     out_t = {"q4_0": Q6_K, "q4_k": Q4_K}.get(recipe, Q6_K)   # stock Q4_0 files carry a Q6_K output tensor
-    w.groups.append(Group([MatMul("output", out_t, n_embd, n_vocab)]))
+    w.groups.append(Group([MatMul("output", out_t, n_embd, n_vocab)], True))
     return w
 
 

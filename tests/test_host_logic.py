@@ -199,3 +199,16 @@ def test_hotpath_rowsplit_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)], res
+
+
+def test_prompt_pass_counts_output_rows_only():
+    """llama-bench's prompt test wants one row of logits: the last layer's FFN and the output projection run at
+    n_outputs = 1 (workload.Group.outputs_only), everything else at n_prompt"""
+    from ggml_hexagon_amd import workload
+    wl = workload.get("llama3-8b-q4_k_m")
+    only = [g for g in wl.groups if g.outputs_only]
+    assert [m.name for g in only for m in g.mats] == ["blk.31.ffn_gate", "blk.31.ffn_up", "blk.31.ffn_down", "output"]
+    full, bench = wl.flops(512), wl.flops(512, 1)
+    saved = sum(m.flops(512) - m.flops(1) for g in only for m in g.mats)
+    assert full - bench == saved and 0.05 < saved / full < 0.12
+    assert wl.flops(1, 1) == wl.flops(1) and wl.algo_bytes(1, 1) == wl.algo_bytes(1)          # token generation is unchanged
