@@ -163,8 +163,13 @@ def _hotpath_worker(rank, world, port, q):
         try:
             qm = _OracleQmm()
             hp = HotPath(qm, wl, torch.device("cpu"), rank, world, rowsplit.RowConcat(), seed=5)
-            for n in (1, 3):
-                hp.run(n)
+            for n, n_out in ((1, None), (3, None), (3, 1)):      # (3, 1): a prompt batch that wants one row of logits
+                if n_out is not None:
+                    for t in hp.prepare(n_out)[2].values():      # stale results of the n = 1 pass must not satisfy the check
+                        t.zero_()
+                hp.run(n, n_out)
+                if n_out is not None:
+                    n = n_out                                   # the last layer's FFN and the output projection ran at n_outputs
                 x, dst_local, dst_full, _ = hp.prepare(n)
                 # every full dst must equal the single-device product of the concatenated shards
                 for grp in wl.groups[-2:]:                       # last layer's ffn_down + the output projection (ragged split)
