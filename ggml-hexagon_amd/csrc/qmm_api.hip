@@ -71,6 +71,10 @@ static int launch_kmix(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const
         case 2: return launch_kmix_n<2>(c, st, g, x, ldx, K);
         case 3: return launch_kmix_n<3>(c, st, g, x, ldx, K);
         case 4: return launch_kmix_n<4>(c, st, g, x, ldx, K);
+        case 5: return launch_kmix_n<5>(c, st, g, x, ldx, K);
+        case 6: return launch_kmix_n<6>(c, st, g, x, ldx, K);
+        case 7: return launch_kmix_n<7>(c, st, g, x, ldx, K);
+        case 8: return launch_kmix_n<8>(c, st, g, x, ldx, K);
         default: return fail(QMM_EINVAL, "kmix matvec: N=%d", N);
     }
 }
@@ -368,7 +372,7 @@ int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, con
         if (rc) return rc;
         if (ws[i].M < 0 || ws[i].ldd < ws[i].M) return fail(QMM_EINVAL, "qmm_mul_mat: ldd < M");
     }
-    if (N <= 4 && nw >= 2 && nw <= MV_MAX_GROUP && c->mv_kmix) {
+    if (N <= QMM_MATVEC_MAX_N && nw >= 2 && nw <= MV_MAX_GROUP && c->mv_kmix) {
         // K-quant matrices of different types share the Q8_K activations: one mixed-type launch for the whole group
         bool kq = true, mixed = false;
         for (int i = 0; i < nw; ++i) {

@@ -187,7 +187,7 @@ def test_group_launch_matches_single(qmm, maybe_ref):
             assert torch.equal(o, qmm.mul_mat(t, w, k, x))
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8])
 def test_mixed_type_group_one_launch(qmm, oracle, n):
     """K-quant matrices of different types sharing src1 go out as ONE mixed-type mat-vec launch (matvec_kmix_kernel):
     every matrix against the oracle, bit-identical to its own single launch, ragged row counts, K = 14336 included"""
