@@ -403,3 +403,31 @@ def test_random_shapes_sweep_every_kernel(qmm, oracle, t):
         assert got.shape == want.shape
         err = rel_rms(got, want) if n <= 8 else rel_l2(got, want)
         assert err < (2e-5 if n <= 8 else 1e-3), (TYPE_NAMES[t], m, k, n, err)
+
+
+def test_bad_arguments_fail_loudly(qmm):
+    """the C-ABI rejects what the kernels do not cover with an error code and a message; nothing falls back, nothing is
+    silently computed: unsupported weight type, K that is not a whole number of blocks, a weight row stride smaller
+    than a row, misaligned or too-short src1 rows, dst rows shorter than M"""
+    from ggml_hexagon_amd.capi import QmmError
+    import ggml_hexagon_amd.synth as synth
+    k, m = 512, 64
+    w = dev(synth.synth_weights(Q4_K, m, k, seed=1))
+    x = torch.zeros((2, k), device="cuda")
+    out = torch.empty((2, m), device="cuda")
+    lib, ctx, st = qmm.lib, qmm.ctx, qmm._stream()
+
+    def call(t=Q4_K, wp=w.data_ptr(), rb=w.stride(0), kk=k, mm=m, xp=x.data_ptr(), n=2, ldx=k, dp=out.data_ptr(), ldd=m):
+        return lib.qmm_mul_mat(ctx, t, wp, rb, kk, mm, xp, n, ldx, dp, ldd, st)
+
+    assert call() == 0
+    assert call(n=0) == 0                                     # empty batch: nothing to do
+    for kwargs, needle in ((dict(t=10), "type"), (dict(t=0), "type"), (dict(kk=k - 32), "multiple"), (dict(rb=w.stride(0) - 2), "stride"),
+                           (dict(xp=x.data_ptr() + 4), "aligned"), (dict(ldx=k - 4), "ldx"), (dict(ldd=m - 1), "ldd")):
+        rc = call(**kwargs)
+        assert rc < 0, kwargs
+        assert needle in lib.qmm_last_error().decode(), (kwargs, lib.qmm_last_error())
+    with pytest.raises(QmmError):
+        qmm.mul_mat(Q8_K, w, k, x)                            # Q8_K is an activation format, not a weight type
+    torch.cuda.synchronize()
+    assert call() == 0                                        # the context is still usable after errors
