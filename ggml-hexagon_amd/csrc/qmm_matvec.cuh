@@ -45,7 +45,10 @@ template <int T, int NTOK> __host__ __device__ inline size_t matvec_lds_bytes(in
 // that surrounds a global_load.  (Measured and dropped: requesting the first slice of a wave's first row
 // before the activation staging.  In-kernel timestamps show the request then completes under the staging,
 // but the kernel's span stays 3.8 us for a 9.4 MB matrix: HBM latency plus 9.4 MB at ~4.5 TB/s.  Also dropped: two
-// adjacent rows per wave step sharing the activation reads: 66 MB at N = 1 15.3 -> 15.9 us, N = 8 unchanged.)
+// adjacent rows per wave step sharing the activation reads: 66 MB at N = 1 15.3 -> 15.9 us, N = 8 unchanged; four
+// slices' loads in flight per wave on K = 14336 rows: 11.5 -> 14.7 us; two Q4_0 blocks per lane and slice: 9.4 MB
+// 6.2 -> 5.8 us but the 7B pass 743 -> 724 tok/s; nontemporal weight loads: 66 MB 15.3 -> 18.5 us.  Every variant that
+// widens a wave's window of outstanding loads loses on the long streams.)
 template <int T, int NTOK>
 __global__ void __launch_bounds__(1024)
 matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t ldx, const int K, const int act_mode) {
