@@ -31,6 +31,11 @@ namespace qmm {
 
 constexpr uint32_t RB_M4 = 0x000f000fu, RB_M8 = 0x00ff00ffu, RB_E = 0x64006400u;
 
+// (x & mask) | exponent-bits is ONE v_and_or_b32 only if at most one of its two constants is a literal: gfx9 allows a single
+// literal / scalar operand per VALU instruction, and with both written as literals hipcc emits v_and + v_or.  Holding the
+// exponent pattern in a VGPR (opaque to constant propagation) gets the fused form: 64 fewer VALU ops per Q4_K block and wave.
+__device__ __forceinline__ uint32_t vgpr_const(uint32_t v) { asm("" : "+v"(v)); return v; }   // not volatile: may be hoisted and shared
+
 template <int T> struct Regb;
 
 // ---- Q4_K ------------------------------------------------------------------------------------------------------------
@@ -54,14 +59,15 @@ template <> struct Regb<T_Q4_K> {
         const _Float16 no0 = (_Float16) (-(dmin * (float) (mn & 0xff))), no1 = (_Float16) (-(dmin * (float) (mn >> 8)));
         const f16x2 DS0 = { ds0, ds0 }, DS1 = { ds1, ds1 }, NO0 = { no0, no0 }, NO1 = { no1, no1 };
         const f16x2 BIAS = { (_Float16) -1024.0f, (_Float16) -1024.0f };
+        const uint32_t E = vgpr_const(RB_E);
         const uint32_t q[4] = { w.qs.x, w.qs.y, w.qs.z, w.qs.w };
         uint32_t lo[8], hi[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            lo[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2((q[i] & RB_M4) | RB_E) + BIAS, DS0, NO0));          // bytes 4i, 4i+2
-            lo[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 8) & RB_M4) | RB_E) + BIAS, DS0, NO0));   // bytes 4i+1, 4i+3
-            hi[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 4) & RB_M4) | RB_E) + BIAS, DS1, NO1));
-            hi[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 12) & RB_M4) | RB_E) + BIAS, DS1, NO1));
+            lo[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2((q[i] & RB_M4) | E) + BIAS, DS0, NO0));          // bytes 4i, 4i+2
+            lo[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 8) & RB_M4) | E) + BIAS, DS0, NO0));   // bytes 4i+1, 4i+3
+            hi[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 4) & RB_M4) | E) + BIAS, DS1, NO1));
+            hi[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 12) & RB_M4) | E) + BIAS, DS1, NO1));
         }
         f[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         f[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
@@ -85,14 +91,15 @@ template <> struct Regb<T_Q4_0> {
     static __device__ __forceinline__ void unpack(const Raw & w, int, uint4 (&f)[4]) {
         const _Float16 d = __builtin_bit_cast(_Float16, (unsigned short) w.d);
         const f16x2 D = { d, d }, BIAS = { (_Float16) -1032.0f, (_Float16) -1032.0f };
+        const uint32_t E = vgpr_const(RB_E);
         const uint32_t q[4] = { w.qs.x, w.qs.y, w.qs.z, w.qs.w };
         uint32_t lo[8], hi[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            lo[2 * i]     = h2_bits((bits_h2((q[i] & RB_M4) | RB_E) + BIAS) * D);
-            lo[2 * i + 1] = h2_bits((bits_h2(((q[i] >> 8) & RB_M4) | RB_E) + BIAS) * D);
-            hi[2 * i]     = h2_bits((bits_h2(((q[i] >> 4) & RB_M4) | RB_E) + BIAS) * D);
-            hi[2 * i + 1] = h2_bits((bits_h2(((q[i] >> 12) & RB_M4) | RB_E) + BIAS) * D);
+            lo[2 * i]     = h2_bits((bits_h2((q[i] & RB_M4) | E) + BIAS) * D);
+            lo[2 * i + 1] = h2_bits((bits_h2(((q[i] >> 8) & RB_M4) | E) + BIAS) * D);
+            hi[2 * i]     = h2_bits((bits_h2(((q[i] >> 4) & RB_M4) | E) + BIAS) * D);
+            hi[2 * i + 1] = h2_bits((bits_h2(((q[i] >> 12) & RB_M4) | E) + BIAS) * D);
         }
         f[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         f[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
@@ -124,16 +131,17 @@ template <> struct Regb<T_Q5_K> {
         const _Float16 no0 = (_Float16) (-(dmin * (float) (mn & 0xff))), no1 = (_Float16) (-(dmin * (float) (mn >> 8)));
         const f16x2 DS0 = { ds0, ds0 }, DS1 = { ds1, ds1 }, NO0 = { no0, no0 }, NO1 = { no1, no1 };
         const f16x2 BIAS = { (_Float16) -1024.0f, (_Float16) -1024.0f };
+        const uint32_t E = vgpr_const(RB_E);
         const uint32_t q[4] = { w.qs.x, w.qs.y, w.qs.z, w.qs.w }, g[4] = { w.qh.x, w.qh.y, w.qh.z, w.qh.w };
         const uint32_t ONE = 0x00010001u;
         uint32_t lo[8], hi[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t gl = g[i] >> (2 * j), gh = g[i] >> (2 * j + 1);
-            lo[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2((q[i] & RB_M4) | ((gl & ONE) << 4) | RB_E) + BIAS, DS0, NO0));
-            lo[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 8) & RB_M4) | (((gl >> 8) & ONE) << 4) | RB_E) + BIAS, DS0, NO0));
-            hi[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 4) & RB_M4) | ((gh & ONE) << 4) | RB_E) + BIAS, DS1, NO1));
-            hi[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 12) & RB_M4) | (((gh >> 8) & ONE) << 4) | RB_E) + BIAS, DS1, NO1));
+            lo[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2((q[i] & RB_M4) | ((gl & ONE) << 4) | E) + BIAS, DS0, NO0));
+            lo[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 8) & RB_M4) | (((gl >> 8) & ONE) << 4) | E) + BIAS, DS0, NO0));
+            hi[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 4) & RB_M4) | ((gh & ONE) << 4) | E) + BIAS, DS1, NO1));
+            hi[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2(((q[i] >> 12) & RB_M4) | (((gh >> 8) & ONE) << 4) | E) + BIAS, DS1, NO1));
         }
         f[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         f[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
@@ -158,13 +166,14 @@ template <> struct Regb<T_Q8_0> {
     static __device__ __forceinline__ void unpack(const Raw & w, int, uint4 (&f)[4]) {
         const _Float16 d = __builtin_bit_cast(_Float16, (unsigned short) w.d);
         const f16x2 D = { d, d }, BIAS = { (_Float16) -1152.0f, (_Float16) -1152.0f };
+        const uint32_t E = vgpr_const(RB_E);
         const uint32_t q[8] = { w.q0.x, w.q0.y, w.q0.z, w.q0.w, w.q1.x, w.q1.y, w.q1.z, w.q1.w };
         uint32_t o[16];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint32_t u = q[i] ^ 0x80808080u;
-            o[2 * i]     = h2_bits((bits_h2((u & RB_M8) | RB_E) + BIAS) * D);            // bytes 4i, 4i+2
-            o[2 * i + 1] = h2_bits((bits_h2(((u >> 8) & RB_M8) | RB_E) + BIAS) * D);     // bytes 4i+1, 4i+3
+            o[2 * i]     = h2_bits((bits_h2((u & RB_M8) | E) + BIAS) * D);            // bytes 4i, 4i+2
+            o[2 * i + 1] = h2_bits((bits_h2(((u >> 8) & RB_M8) | E) + BIAS) * D);     // bytes 4i+1, 4i+3
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) f[kk] = make_uint4(o[4 * kk], o[4 * kk + 1], o[4 * kk + 2], o[4 * kk + 3]);
@@ -197,6 +206,7 @@ template <> struct Regb<T_Q6_K> {
     static __device__ __forceinline__ void unpack_half(const Raw & w, int h, uint4 (&f)[4]) {
         const float d = h2f(w.d);
         const f16x2 BIAS = { (_Float16) -1056.0f, (_Float16) -1056.0f };
+        const uint32_t E = vgpr_const(RB_E);
         const uint32_t A[4] = { w.qa.x, w.qa.y, w.qa.z, w.qa.w }, B[4] = { w.qb.x, w.qb.y, w.qb.z, w.qb.w },
                        H[4] = { w.qh.x, w.qh.y, w.qh.z, w.qh.w };
         uint32_t o[2][8];
@@ -209,8 +219,8 @@ template <> struct Regb<T_Q6_K> {
             for (int q = 0; q < 2; ++q) {
                 const _Float16 t = (_Float16) (d * (float) scale(w, h, 2 * HF + q));
                 const f16x2 DS = { t, t };
-                o[q][2 * i]     = h2_bits((bits_h2((v[q] & RB_M8) | RB_E) + BIAS) * DS);            // l = 4i, 4i+2
-                o[q][2 * i + 1] = h2_bits((bits_h2(((v[q] >> 8) & RB_M8) | RB_E) + BIAS) * DS);     // l = 4i+1, 4i+3
+                o[q][2 * i]     = h2_bits((bits_h2((v[q] & RB_M8) | E) + BIAS) * DS);            // l = 4i, 4i+2
+                o[q][2 * i + 1] = h2_bits((bits_h2(((v[q] >> 8) & RB_M8) | E) + BIAS) * DS);     // l = 4i+1, 4i+3
             }
         }
 #pragma unroll
@@ -479,10 +489,11 @@ __device__ __forceinline__ RegbFrag regb_unpack_q4k(const uint4 qs, const uint4 
     // low nibbles: (b & 0xf) | 0x6400 = 1024 + n; high nibbles in place: (b & 0xf0) | 0x5400 = 64 + n (ulp of 64.0 is 1/16):
     // one shift per dword instead of three, same values
     const f16x2 BIAS_H = { (_Float16) -64.0f, (_Float16) -64.0f };
+    const uint32_t E = vgpr_const(0x64006400u), EH = vgpr_const(0x54005400u);
     uint32_t lo[8], hi[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint32_t M = 0x000f000fu, E = 0x64006400u, MH = 0x00f000f0u, EH = 0x54005400u;
+        const uint32_t M = 0x000f000fu, MH = 0x00f000f0u;
         const uint32_t w8 = w[i] >> 8;
         lo[2 * i]     = h2_bits(__builtin_elementwise_fma(bits_h2((w[i] & M) | E) + BIAS, DS0, NO0));         // bytes 4i, 4i+2
         lo[2 * i + 1] = h2_bits(__builtin_elementwise_fma(bits_h2((w8 & M) | E) + BIAS, DS0, NO0));           // bytes 4i+1, 4i+3
