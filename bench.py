@@ -44,12 +44,18 @@ def roofline_leg(hp, q, n_batch, torch, n_outputs=None):
         x, dst_local, _, ids = hp.prepare(n_tokens)
         m0 = grp.mats[0]
         if m0.n_expert:
-            for m in grp.mats:
-                ne11 = m.n_used if m.name.endswith("down_exps") else 1
-                w, _ = hp.weights[m.name]
-                fn = (lambda m=m, w=w, ne11=ne11, x=x, ids=ids, dst_local=dst_local:
-                      q.mul_mat_id(m.type, w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=dst_local[("id", m.M)]))
-                buckets.setdefault(("id", m.type, n_tokens > 8), []).append((fn, m.algo_bytes(n_tokens), m.flops(n_tokens)))
+            ne11 = m0.n_used if m0.name.endswith("down_exps") else 1
+            ws = [hp.weights[m.name][0] for m in grp.mats]
+            outs = [dst_local[("id", m.name.split(".")[-1], m.M)] for m in grp.mats]
+            if len(grp.mats) == 2 and grp.mats[1].type == m0.type:
+                fn = (lambda m0=m0, ws=ws, outs=outs, ne11=ne11, x=x, ids=ids:
+                      q.mul_mat_id_pair(m0.type, ws[0], ws[1], m0.K, x[(m0.K, ne11)], ids[:, :m0.n_used], outs[0], outs[1]))
+                buckets.setdefault(("id", m0.type, n_tokens > 8), []).append(
+                    (fn, sum(m.algo_bytes(n_tokens) for m in grp.mats) - n_tokens * m0.K * 4, sum(m.flops(n_tokens) for m in grp.mats)))
+            else:
+                for m, w, o in zip(grp.mats, ws, outs):
+                    fn = (lambda m=m, w=w, o=o, ne11=ne11, x=x, ids=ids: q.mul_mat_id(m.type, w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=o))
+                    buckets.setdefault(("id", m.type, n_tokens > 8), []).append((fn, m.algo_bytes(n_tokens), m.flops(n_tokens)))
             continue
         # one launch per run of same-type weights inside the group (that is how qmm_mul_mat_group issues them)
         i = 0

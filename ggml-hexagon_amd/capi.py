@@ -18,7 +18,7 @@ EXPORTS = [
     "qmm_memcpy_d2h", "qmm_memcpy_d2d", "qmm_memset", "qmm_synchronize", "qmm_memcpy2d_d2d", "qmm_event_create",
     "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_memcpy_h2d_async",
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_dequantize",
-    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_id",
+    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
 ]
 
 
@@ -68,6 +68,7 @@ def load_library() -> C.CDLL:
     lib.qmm_mul_mat.argtypes = [v, i32, v, i64, i64, i64, v, i64, i64, v, i64, v]
     lib.qmm_mul_mat_group.argtypes = [v, C.POINTER(QmmWeight), i32, i64, v, i64, i64, v]
     lib.qmm_mul_mat_id.argtypes = [v, i32, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, i64, i64, v]
+    lib.qmm_mul_mat_id_pair.argtypes = [v, i32, v, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, v, i64, i64, v]
     return lib
 
 
@@ -165,3 +166,15 @@ class Qmm:
                                           ids.data_ptr(), n_used, n_tokens, ids.stride(0) * 4,
                                           out.data_ptr(), out.stride(1) * 4, out.stride(0) * 4, self._stream()))
         return out
+
+    def mul_mat_id_pair(self, t, w0, w1, k, b, ids, out0, out1):
+        """two expert tensors of one type and shape on the same b and ids (ffn_gate_exps + ffn_up_exps)"""
+        n_expert, m = w0.shape[0], w0.shape[1]
+        n_tokens, ne11 = b.shape[0], b.shape[1]
+        n_used = ids.shape[1]
+        assert ids.stride(1) == 1 and w1.shape == w0.shape and w1.stride() == w0.stride() and out0.stride() == out1.stride()
+        self._chk(self.lib.qmm_mul_mat_id_pair(self.ctx, t, w0.data_ptr(), w1.data_ptr(), w0.stride(1), w0.stride(0), k, m, n_expert,
+                                               b.data_ptr(), ne11, b.stride(1) * 4, b.stride(0) * 4,
+                                               ids.data_ptr(), n_used, n_tokens, ids.stride(0) * 4,
+                                               out0.data_ptr(), out1.data_ptr(), out0.stride(1) * 4, out0.stride(0) * 4, self._stream()))
+        return out0, out1

@@ -413,9 +413,33 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, const ggml_tensor * c
     return GGML_STATUS_SUCCESS;
 }
 
-enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, const ggml_tensor * dst) {
+// ffn_gate_exps and ffn_up_exps are consecutive MUL_MAT_ID nodes on the same src1 and ids (llama.cpp build_moe_ffn): when the
+// next node is such a twin, both go out in one call (one mat-vec launch, or one expert sort + activation prep)
+bool moe_twin(const ggml_tensor * d0, const ggml_tensor * d1) {
+    if (d1->op != GGML_OP_MUL_MAT_ID || !supports_mul_mat_id(d1)) return false;
+    const ggml_tensor * a0 = d0->src[0], * a1 = d1->src[0];
+    if (d0->src[1] != d1->src[1] || d0->src[2] != d1->src[2] || a0 == a1 || !is_ours(a1) || !is_ours(d1)) return false;
+    if (a0->type != a1->type || !ggml_are_same_shape(a0, a1) || a0->nb[1] != a1->nb[1] || a0->nb[2] != a1->nb[2]) return false;
+    return d0->nb[1] == d1->nb[1] && d0->nb[2] == d1->nb[2] && ggml_are_same_shape(d0, d1);
+}
+
+enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, const ggml_tensor * const * nodes, int n_nodes, int * consumed) {
+    const ggml_tensor * dst = nodes[0];
     const ggml_tensor * as = dst->src[0], * b = dst->src[1], * ids = dst->src[2];
     qmm_ctx * q = ctx->dev->qmm;
+    *consumed = 1;
+    if (n_nodes > 1 && moe_twin(dst, nodes[1])) {
+        const ggml_tensor * dst1 = nodes[1];
+        if (qmm_mul_mat_id_pair(q, as->type, as->data, dst1->src[0]->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
+                                (const float *) b->data, b->ne[1], b->nb[1], b->nb[2],
+                                (const int32_t *) ids->data, ids->ne[0], ids->ne[1], ids->nb[1],
+                                (float *) dst->data, (float *) dst1->data, dst->nb[1], dst->nb[2], qmm_stream(q))) {
+            GGML_LOG_ERROR("MI355X MUL_MAT_ID(%s, %s): %s\n", dst->name, dst1->name, qmm_last_error());
+            return GGML_STATUS_FAILED;
+        }
+        *consumed = 2;
+        return GGML_STATUS_SUCCESS;
+    }
     if (qmm_mul_mat_id(q, as->type, as->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
                        (const float *) b->data, b->ne[1], b->nb[1], b->nb[2],
                        (const int32_t *) ids->data, ids->ne[0], ids->ne[1], ids->nb[1],
@@ -504,7 +528,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         if (node->op == GGML_OP_MUL_MAT) {
             st = compute_mul_mat(ctx, cgraph->nodes + i, cgraph->n_nodes - i, &consumed);
         } else if (node->op == GGML_OP_MUL_MAT_ID) {
-            st = compute_mul_mat_id(ctx, node);
+            st = compute_mul_mat_id(ctx, cgraph->nodes + i, cgraph->n_nodes - i, &consumed);
         } else {
             GGML_LOG_ERROR("MI355X: op %s (%s) is outside the offloaded surface\n", ggml_op_name(node->op), node->name);
             st = GGML_STATUS_FAILED;

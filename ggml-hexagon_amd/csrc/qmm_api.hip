@@ -468,4 +468,21 @@ int qmm_mul_mat_id(qmm_ctx * c, int type, const void * as, int64_t rb, int64_t e
                           ids, n_used, n_tokens, ids_nb1, dst, d_nb1, d_nb2);
 }
 
+int qmm_mul_mat_id_pair(qmm_ctx * c, int type, const void * as0, const void * as1, int64_t rb, int64_t expert_bytes,
+                        int64_t K, int64_t M, int64_t n_expert,
+                        const float * b, int64_t ne11, int64_t b_nb1, int64_t b_nb2,
+                        const int32_t * ids, int64_t n_used, int64_t n_tokens, int64_t ids_nb1,
+                        float * dst0, float * dst1, int64_t d_nb1, int64_t d_nb2, void * stream) {
+    if (!c) return fail(QMM_EINVAL, "null ctx");
+    if (!as1 || !dst1) return fail(QMM_EINVAL, "qmm_mul_mat_id_pair: second tensor missing");
+    int rc = check_mm(type, as0, rb, K, b, K, "qmm_mul_mat_id_pair");
+    if (rc) return rc;
+    if (b_nb1 % 16 || b_nb2 % 16 || ids_nb1 % 4 || d_nb1 % 4 || d_nb2 % 4 || expert_bytes % 2 || (ne11 != 1 && ne11 != n_used))
+        return fail(QMM_EINVAL, "qmm_mul_mat_id_pair: strides / ne11");
+    if (n_tokens <= 0 || n_used <= 0 || M <= 0) return QMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    return moe_mul_mat_id(c, c->s(stream), type, as0, rb, expert_bytes, K, M, n_expert, b, ne11, b_nb1, b_nb2,
+                          ids, n_used, n_tokens, ids_nb1, dst0, d_nb1, d_nb2, as1, dst1);
+}
+
 } // extern "C"

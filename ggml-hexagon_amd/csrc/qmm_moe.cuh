@@ -23,7 +23,9 @@ __global__ void __launch_bounds__(1024)
 matvec_id_kernel(const uint8_t * __restrict__ as, const int64_t row_bytes, const int64_t expert_bytes, const int K, const int M,
                  const int n_expert, const float * __restrict__ b, const int ne11, const int64_t b_s1, const int64_t b_s2,
                  const int32_t * __restrict__ ids, const int n_used, const int64_t ids_s1,
-                 float * __restrict__ dst, const int64_t d_s1, const int64_t d_s2, const int act_mode, int * __restrict__ flag) {
+                 float * __restrict__ dst, const int64_t d_s1, const int64_t d_s2, const int act_mode, int * __restrict__ flag,
+                 const uint8_t * __restrict__ as2, float * __restrict__ dst2) {
+    // blockIdx.z = 1: the second expert tensor of a pair that shares b and ids (ffn_gate_exps / ffn_up_exps)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int ACT = Traits<T>::ACT;
     int8_t *  aq = reinterpret_cast<int8_t *>(smem);
@@ -38,8 +40,8 @@ matvec_id_kernel(const uint8_t * __restrict__ as, const int64_t row_bytes, const
     }
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = blockDim.x / WAVE;
     const int units = K / MvUnit<T>::W;
-    const uint8_t * We = as + (int64_t) e * expert_bytes;
-    float * out = dst + (int64_t) t * d_s2 + (int64_t) s * d_s1;
+    const uint8_t * We = (blockIdx.z ? as2 : as) + (int64_t) e * expert_bytes;
+    float * out = (blockIdx.z ? dst2 : dst) + (int64_t) t * d_s2 + (int64_t) s * d_s1;
 
     int row = blockIdx.y * nwaves + wave;
     MvUnit<T> pre;
@@ -109,18 +111,18 @@ moe_sort_kernel(const int32_t * __restrict__ ids, const int64_t ids_s1, const in
 template <int T>
 inline int launch_matvec_id(qmm_ctx * c, hipStream_t st, const void * as, int64_t rb, int64_t eb, int K, int M, int n_expert,
                             const float * b, int ne11, int64_t b_s1, int64_t b_s2, const int32_t * ids, int n_used, int n_tokens,
-                            int64_t ids_s1, float * dst, int64_t d_s1, int64_t d_s2) {
+                            int64_t ids_s1, float * dst, int64_t d_s1, int64_t d_s2, const void * as2 = nullptr, float * dst2 = nullptr) {
     const size_t lds = matvec_lds_bytes<T, 1>(K);
     auto kern = matvec_id_kernel<T>;
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    const int P = n_used * n_tokens;
+    const int P = n_used * n_tokens, nm = as2 ? 2 : 1;
     const int nw = 8;
     int by = (M + nw - 1) / nw;
-    const int cap = (2 * c->cus + P - 1) / P;
+    const int cap = (2 * c->cus + P * nm - 1) / (P * nm);
     if (by > cap) by = cap;
     if (by < 1) by = 1;
-    hipLaunchKernelGGL(kern, dim3(P, by), dim3(nw * WAVE), lds, st, (const uint8_t *) as, rb, eb, K, M, n_expert, b, ne11, b_s1, b_s2,
-                       ids, n_used, ids_s1, dst, d_s1, d_s2, c->act_mode, c->flag);
+    hipLaunchKernelGGL(kern, dim3(P, by, nm), dim3(nw * WAVE), lds, st, (const uint8_t *) as, rb, eb, K, M, n_expert, b, ne11, b_s1, b_s2,
+                       ids, n_used, ids_s1, dst, d_s1, d_s2, c->act_mode, c->flag, (const uint8_t *) as2, dst2);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }
@@ -128,13 +130,15 @@ inline int launch_matvec_id(qmm_ctx * c, hipStream_t st, const void * as, int64_
 inline int moe_mul_mat_id(qmm_ctx * c, hipStream_t st, int type, const void * as, int64_t rb, int64_t eb, int64_t K, int64_t M,
                           int64_t n_expert, const float * b, int64_t ne11, int64_t b_nb1, int64_t b_nb2,
                           const int32_t * ids, int64_t n_used, int64_t n_tokens, int64_t ids_nb1,
-                          float * dst, int64_t d_nb1, int64_t d_nb2) {
+                          float * dst, int64_t d_nb1, int64_t d_nb2, const void * as2 = nullptr, float * dst2 = nullptr) {
+    // as2 / dst2: a second expert tensor of the same type and shape on the same b and ids (ffn_gate_exps + ffn_up_exps): one
+    // mat-vec launch for both, or one sort + one activation prep for both
     const int64_t b_s1 = b_nb1 / 4, b_s2 = b_nb2 / 4, d_s1 = d_nb1 / 4, d_s2 = d_nb2 / 4, ids_s1 = ids_nb1 / 4;
     const int64_t P = n_used * n_tokens;
     if (P <= 16) {
 #define QMM_MVID(TT)                                                                                                                  \
     return launch_matvec_id<TT>(c, st, as, rb, eb, (int) K, (int) M, (int) n_expert, b, (int) ne11, b_s1, b_s2, ids, (int) n_used, \
-                                (int) n_tokens, ids_s1, dst, d_s1, d_s2)
+                                (int) n_tokens, ids_s1, dst, d_s1, d_s2, as2, dst2)
         switch (type) {
             case T_Q4_0: QMM_MVID(T_Q4_0);
             case T_Q8_0: QMM_MVID(T_Q8_0);
@@ -169,8 +173,12 @@ inline int moe_mul_mat_id(qmm_ctx * c, hipStream_t st, int type, const void * as
               : launch_prep<T_Q8_K>(c, st, type, b, 0, gather, n_live, (int) P, (int) P, (int) K, Kp, frag, xh, scale);
     if (rc) return rc;
     MfmaOperand op = { xh, scale, Kp, frag };
-    return launch_mfma_any(c, st, type, as, rb, eb, (int) n_expert, (int) M, (int) K, op, seg_start, seg_count, (int) P,
-                           (int) ((P + 127) / 128), dst, 0, dst_off);
+    rc = launch_mfma_any(c, st, type, as, rb, eb, (int) n_expert, (int) M, (int) K, op, seg_start, seg_count, (int) P,
+                         (int) ((P + 127) / 128), dst, 0, dst_off);
+    if (rc || !as2) return rc;
+    const int64_t shift = dst2 - dst;                         // same scatter pattern, other destination tensor
+    return launch_mfma_any(c, st, type, as2, rb, eb, (int) n_expert, (int) M, (int) K, op, seg_start, seg_count, (int) P,
+                           (int) ((P + 127) / 128), dst + shift, 0, dst_off);
 }
 
 } // namespace qmm

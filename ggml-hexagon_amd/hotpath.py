@@ -55,7 +55,7 @@ class HotPath:
                         x[key] = torch.rand((n_tokens, ne11, m.K), device=self.dev, generator=g) * 2 - 1
                     if ids is None:     # per token: a shuffle of the experts, first n_used taken (test-backend-ops.cpp:2113-2132)
                         ids = torch.stack([torch.randperm(m.n_expert, device=self.dev, generator=g) for _ in range(n_tokens)]).to(torch.int32)
-                    dkey = ("id", m.M)
+                    dkey = ("id", m.name.split(".")[-1], m.M)     # paired launches (gate_exps + up_exps) write distinct buffers
                     if dkey not in dst_local:
                         dst_local[dkey] = torch.empty((n_tokens, m.n_used, m.M), device=self.dev)
                 else:
@@ -83,10 +83,14 @@ class HotPath:
             x, dst_local, dst_full, ids = io_out if grp.outputs_only else io_all
             m0 = grp.mats[0]
             if m0.n_expert:
-                for m in grp.mats:
-                    ne11 = m.n_used if m.name.endswith("down_exps") else 1
-                    w, _ = self.weights[m.name]
-                    q.mul_mat_id(m.type, w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=dst_local[("id", m.M)])
+                ne11 = m0.n_used if m0.name.endswith("down_exps") else 1
+                outs = [dst_local[("id", m.name.split(".")[-1], m.M)] for m in grp.mats]
+                if len(grp.mats) == 2 and grp.mats[1].type == m0.type:      # ffn_gate_exps + ffn_up_exps: same b, same ids
+                    q.mul_mat_id_pair(m0.type, self.weights[grp.mats[0].name][0], self.weights[grp.mats[1].name][0], m0.K,
+                                      x[(m0.K, ne11)], ids[:, :m0.n_used], outs[0], outs[1])
+                else:
+                    for m, o in zip(grp.mats, outs):
+                        q.mul_mat_id(m.type, self.weights[m.name][0], m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=o)
                 continue
             ws, outs, keys = [], [], []
             for m in grp.mats:

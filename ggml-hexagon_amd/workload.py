@@ -98,8 +98,8 @@ def _llama(name, n_layer, n_embd, n_ff, n_head, n_head_kv, n_vocab, recipe, n_ex
         w.groups.append(Group([MatMul(f"blk.{i}.attn_output", to, n_embd, n_embd)]))
         last = i == n_layer - 1                      # its FFN runs on the output rows only in a prompt batch (Group docstring)
         if n_expert:
-            w.groups.append(Group([MatMul(f"blk.{i}.ffn_gate_exps", tg, n_embd, n_ff, n_expert, n_used)], last))
-            w.groups.append(Group([MatMul(f"blk.{i}.ffn_up_exps", tg, n_embd, n_ff, n_expert, n_used)], last))
+            w.groups.append(Group([MatMul(f"blk.{i}.ffn_gate_exps", tg, n_embd, n_ff, n_expert, n_used),
+                                   MatMul(f"blk.{i}.ffn_up_exps", tg, n_embd, n_ff, n_expert, n_used)], last))
             w.groups.append(Group([MatMul(f"blk.{i}.ffn_down_exps", td, n_ff, n_embd, n_expert, n_used)], last))
         else:
             w.groups.append(Group([MatMul(f"blk.{i}.ffn_gate", tg, n_embd, n_ff), MatMul(f"blk.{i}.ffn_up", tg, n_embd, n_ff)], last))

@@ -154,6 +154,15 @@ QMM_API int qmm_mul_mat_id(qmm_ctx * ctx, int type, const void * as, int64_t w_r
                            const int32_t * ids, int64_t n_used, int64_t n_tokens, int64_t ids_nb1,
                            float * dst, int64_t d_nb1, int64_t d_nb2, void * stream);
 
+/* Two expert tensors of the same type and shape on the SAME b and ids — ffn_gate_exps and ffn_up_exps, consecutive nodes of
+ * llama.cpp's MoE block (src/llama-graph.cpp build_moe_ffn): one mat-vec launch for both at small batches, one expert sort
+ * and one activation prep for both at large ones.  dst0 / dst1 have the same strides. */
+QMM_API int qmm_mul_mat_id_pair(qmm_ctx * ctx, int type, const void * as0, const void * as1, int64_t w_row_bytes, int64_t expert_bytes,
+                                int64_t K, int64_t M, int64_t n_expert,
+                                const float * b, int64_t ne11, int64_t b_nb1, int64_t b_nb2,
+                                const int32_t * ids, int64_t n_used, int64_t n_tokens, int64_t ids_nb1,
+                                float * dst0, float * dst1, int64_t d_nb1, int64_t d_nb2, void * stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,6 +297,27 @@ def test_mul_mat_id_vs_oracle(qmm, oracle, t, n_tokens, n_expert, n_used):
     qmm.synchronize()
 
 
+@pytest.mark.parametrize("t", (Q4_K, Q8_0), ids=["q4_K", "q8_0"])
+@pytest.mark.parametrize("n_tokens", [1, 4, 40, 300])
+def test_mul_mat_id_pair_matches_two_calls(qmm, oracle, t, n_tokens):
+    """ffn_gate_exps + ffn_up_exps in one call (one mat-vec launch / one sort + prep) == the two single calls, and the oracle"""
+    import ggml_hexagon_amd.synth as synth
+    k, m, n_expert, n_used = 256 if t == Q4_K else 128, 96, 8, 2
+    rng = np.random.default_rng(n_tokens)
+    w0 = synth.synth_weights(t, n_expert * m, k, seed=1, sigma=0.25).reshape(n_expert, m, -1)
+    w1 = synth.synth_weights(t, n_expert * m, k, seed=2, sigma=0.25).reshape(n_expert, m, -1)
+    ids = np.ascontiguousarray(np.stack([rng.permutation(n_expert) for _ in range(n_tokens)]).astype(np.int32)[:, :n_used])
+    b = rng.uniform(-1, 1, (n_tokens, 1, k)).astype(np.float32)
+    o0 = torch.full((n_tokens, n_used, m), 2.0, device="cuda")
+    o1 = torch.full((n_tokens, n_used, m), 2.0, device="cuda")
+    qmm.mul_mat_id_pair(t, dev(w0), dev(w1), k, dev(b), dev(ids), o0, o1)
+    for w, o in ((w0, o0), (w1, o1)):
+        assert torch.equal(o, qmm.mul_mat_id(t, dev(w), k, dev(b), dev(ids)))
+        want = oracle.mul_mat_id(t, w, k, m, b, ids, ACT_REF)
+        err = rel_rms(o.cpu().numpy(), want) if n_tokens * n_used <= 16 else rel_l2(o.cpu().numpy(), want)
+        assert err < (2e-5 if n_tokens * n_used <= 16 else 1e-3)
+
+
 def test_mul_mat_id_bad_expert_is_reported(qmm):
     import ggml_hexagon_amd.synth as synth
     from ggml_hexagon_amd.capi import QmmError

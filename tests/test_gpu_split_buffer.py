@@ -43,3 +43,16 @@ def test_async_transfers_and_events():
     out = p.stdout + p.stderr
     m = re.search(r"(\d+) OK, (\d+) FAILED", out)
     assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) >= 9, out[-3000:]
+
+
+def test_moe_twin_nodes_go_out_as_one_call():
+    """two MUL_MAT_ID nodes on the same src1 and ids in one graph (ffn_up_exps / ffn_gate_exps): the plugin pairs them
+    (qmm_mul_mat_id_pair); both results against the CPU backend (tests/cpp/test_moe_pair.cpp)"""
+    exe = ROOT / "oracle" / "_ref" / "test-moe-pair"
+    if not exe.exists() or not PLUGIN.exists():
+        pytest.skip("oracle/_ref/test-moe-pair or the plugin module is not built (needs the reference tree at build time)")
+    env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN))
+    p = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=600, cwd=str(exe.parent))
+    out = p.stdout + p.stderr
+    m = re.search(r"(\d+) OK, (\d+) FAILED", out)
+    assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) >= 18, out[-3000:]
