@@ -169,13 +169,21 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # rehearsal aids for a one-GPU box (the driver's multi-GPU runs use neither): QMM_BENCH_DEVICE pins every rank to one
+    # device, QMM_BENCH_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks on one device
+    if os.environ.get("QMM_BENCH_DEVICE"):
+        local = int(os.environ["QMM_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("QMM_BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ggml_hexagon_amd import workload
     from ggml_hexagon_amd.capi import Qmm
