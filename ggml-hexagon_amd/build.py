@@ -23,17 +23,27 @@ def _newer(target: Path, sources) -> bool:
 
 
 def build_qmm(force: bool = False) -> Path:
-    """the kernel library behind include/ggml_mi355x_qmm.h"""
-    srcs = sorted(CSRC.glob("qmm_*")) + [ROOT / "include" / "ggml_mi355x_qmm.h"]
-    if not force and _newer(QMM_SO, srcs):
+    """the kernel library behind include/ggml_mi355x_qmm.h and include/ggml_mi355x_ops.h: one object per translation unit
+    (qmm_api.hip = the quantized MUL_MAT path, qmm_ops.hip = the glue ops), rebuilt only when its sources changed"""
+    headers = sorted(CSRC.glob("qmm_*.cuh")) + sorted(CSRC.glob("qmm_*.h")) + sorted((ROOT / "include").glob("ggml_mi355x_*.h"))
+    units = [CSRC / "qmm_api.hip", CSRC / "qmm_ops.hip"]
+    if not force and _newer(QMM_SO, units + headers):
         return QMM_SO
     if not shutil.which(HIPCC):
         if QMM_SO.exists():
             return QMM_SO
         raise RuntimeError("hipcc not found and no prebuilt libggml_mi355x_qmm.so")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fno-slp-vectorize",
-           "-o", str(QMM_SO), str(CSRC / "qmm_api.hip")]
-    subprocess.run(cmd, check=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-slp-vectorize"]
+    objs, jobs = [], []
+    for u in units:
+        obj = CSRC / (u.stem + ".o")
+        objs.append(obj)
+        if force or not _newer(obj, [u] + headers):
+            jobs.append(subprocess.Popen([HIPCC, *flags, "-c", str(u), "-o", str(obj)]))
+    for j in jobs:
+        if j.wait() != 0:
+            raise subprocess.CalledProcessError(j.returncode, j.args)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(QMM_SO), *map(str, objs)], check=True)
     return QMM_SO
 
 
@@ -48,7 +58,7 @@ def build_plugin(force: bool = False) -> Path | None:
     src = CSRC / "ggml-mi355x.cpp"
     if not src.exists():
         return None
-    srcs = [src, ROOT / "include" / "ggml-mi355x.h", ROOT / "include" / "ggml_mi355x_qmm.h"]
+    srcs = [src, ROOT / "include" / "ggml-mi355x.h", ROOT / "include" / "ggml_mi355x_qmm.h", ROOT / "include" / "ggml_mi355x_ops.h"]
     if not force and _newer(PLUGIN_SO, srcs + [QMM_SO]):
         return PLUGIN_SO
     if not have_ggml_headers() or not (shutil.which("g++") or shutil.which("c++")):

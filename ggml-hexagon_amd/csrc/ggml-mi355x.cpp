@@ -17,7 +17,9 @@
 #include "ggml-backend-impl.h"
 #include "ggml-impl.h"
 #include "ggml_mi355x_qmm.h"
+#include "ggml_mi355x_ops.h"
 
+#include <algorithm>
 #include <array>
 #include <cstdio>
 #include <cstdlib>
@@ -54,7 +56,19 @@ struct mi355x_backend_ctx {
     mi355x_device_ctx * dev;
     std::string         name;
     qmm_event *         ev_copy = nullptr;   // cpy_tensor_async: "src is ready" on the source backend's stream
+    std::vector<const ggml_tensor *> fuse_cand;      // scratch of graph_compute's fusion pass
+    std::vector<int>                 fuse_uses;
 };
+
+// GGML_MI355X_GLUE=0: offload the quantized MUL_MAT / MUL_MAT_ID only (the round-1 surface); GGML_MI355X_FUSE=0: no fused pairs
+bool GGML_MI355X_GLUE_OFF() {
+    static const bool off = [] { const char * e = getenv("GGML_MI355X_GLUE"); return e && atoi(e) == 0; }();
+    return off;
+}
+bool GGML_MI355X_FUSE_OFF() {
+    static const bool off = [] { const char * e = getenv("GGML_MI355X_FUSE"); return e && atoi(e) == 0; }();
+    return off;
+}
 
 mi355x_device_ctx      g_devs[GGML_MI355X_MAX_DEVICES];
 ggml_backend_device    g_devices[GGML_MI355X_MAX_DEVICES];
@@ -450,6 +464,92 @@ enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, const ggml_tensor 
     return GGML_STATUS_SUCCESS;
 }
 
+
+// ---- glue ops: everything between the quantized MUL_MATs of a layer, so that a layer is one split.
+// The kernel library decides what it implements (qmm_op_supported); this side only translates ggml nodes.
+
+qmm_tensor to_qt(const ggml_tensor * t) {
+    qmm_tensor q{};
+    q.data = t->data;
+    q.type = (int32_t) t->type;
+    for (int i = 0; i < 4; ++i) { q.ne[i] = t->ne[i]; q.nb[i] = (int64_t) t->nb[i]; }
+    memcpy(q.op_params, t->op_params, sizeof(q.op_params));
+    return q;
+}
+
+// ggml node -> library op; 0 when the node is not a glue op of this backend
+int glue_op(const ggml_tensor * node) {
+    switch (node->op) {
+        case GGML_OP_ADD:      return QMM_OP_ADD;
+        case GGML_OP_SUB:      return QMM_OP_SUB;
+        case GGML_OP_MUL:      return QMM_OP_MUL;
+        case GGML_OP_DIV:      return QMM_OP_DIV;
+        case GGML_OP_SCALE:    return QMM_OP_SCALE;
+        case GGML_OP_RMS_NORM: return QMM_OP_RMS_NORM;
+        case GGML_OP_ROPE:     return QMM_OP_ROPE;
+        case GGML_OP_SOFT_MAX: return QMM_OP_SOFT_MAX;
+        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: return QMM_OP_CPY;
+        case GGML_OP_GET_ROWS: return QMM_OP_GET_ROWS;
+        case GGML_OP_MUL_MAT:  return node->src[0] && (node->src[0]->type == GGML_TYPE_F16 || node->src[0]->type == GGML_TYPE_F32) ? QMM_OP_MUL_MAT_F : 0;
+        case GGML_OP_UNARY:
+            switch (ggml_get_unary_op(node)) {
+                case GGML_UNARY_OP_SILU:       return QMM_OP_SILU;
+                case GGML_UNARY_OP_GELU:       return QMM_OP_GELU;
+                case GGML_UNARY_OP_GELU_QUICK: return QMM_OP_GELU_QUICK;
+                case GGML_UNARY_OP_RELU:       return QMM_OP_RELU;
+                case GGML_UNARY_OP_TANH:       return QMM_OP_TANH;
+                case GGML_UNARY_OP_SIGMOID:    return QMM_OP_SIGMOID;
+                case GGML_UNARY_OP_NEG:        return QMM_OP_NEG;
+                case GGML_UNARY_OP_EXP:        return QMM_OP_EXP;
+                default:                       return 0;
+            }
+        default: return 0;
+    }
+}
+
+// the operands as the library wants them: CPY's dst is src[1]'s layout (the node itself is a view of it)
+bool supports_glue(const ggml_tensor * node) {
+    const int op = glue_op(node);
+    if (!op) return false;
+    if (GGML_MI355X_GLUE_OFF()) return false;
+    qmm_tensor s[3];
+    const qmm_tensor * ps[3] = { nullptr, nullptr, nullptr };
+    for (int i = 0; i < 3; ++i)
+        if (node->src[i]) { s[i] = to_qt(node->src[i]); ps[i] = &s[i]; }
+    const qmm_tensor d = to_qt(node);
+    if (op == QMM_OP_CPY) return qmm_op_supported(op, ps[0], nullptr, nullptr, &d) != 0;
+    return qmm_op_supported(op, ps[0], ps[1], ps[2], &d) != 0;
+}
+
+enum ggml_status compute_glue(mi355x_backend_ctx * ctx, const ggml_tensor * node, int op, const ggml_tensor * s0, const ggml_tensor * s1,
+                              const ggml_tensor * s2) {
+    qmm_tensor s[3];
+    const qmm_tensor * ps[3] = { nullptr, nullptr, nullptr };
+    const ggml_tensor * srcs[3] = { s0, s1, s2 };
+    for (int i = 0; i < 3; ++i)
+        if (srcs[i]) { s[i] = to_qt(srcs[i]); ps[i] = &s[i]; }
+    const qmm_tensor d = to_qt(node);
+    if (qmm_op_compute(ctx->dev->qmm, op, ps[0], ps[1], ps[2], &d, qmm_stream(ctx->dev->qmm))) {
+        GGML_LOG_ERROR("MI355X %s(%s): %s\n", ggml_op_name(node->op), node->name, qmm_last_error());
+        return GGML_STATUS_FAILED;
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+// Pairs the library runs as one launch: RMS_NORM -> MUL by a one-row weight (build_norm), SILU -> MUL (build_ffn's SwiGLU).
+// Legal only when the first node's result has no other reader: `single_use` is computed per graph in graph_compute.
+int fused_pair(const ggml_tensor * n0, const ggml_tensor * n1, const ggml_tensor ** other) {
+    if (n1->op != GGML_OP_MUL || (n1->src[0] != n0 && n1->src[1] != n0) || n1->src[0] == n1->src[1]) return 0;
+    *other = n1->src[0] == n0 ? n1->src[1] : n1->src[0];
+    if (!ggml_are_same_shape(n0, n1) || (n0->flags & GGML_TENSOR_FLAG_OUTPUT)) return 0;
+    qmm_tensor a = to_qt(n0->src[0]), b = to_qt(*other), d = to_qt(n1);
+    memcpy(d.op_params, n0->op_params, sizeof(d.op_params));
+    if (n0->op == GGML_OP_RMS_NORM && qmm_op_supported(QMM_OP_RMS_NORM_MUL, &a, &b, nullptr, &d)) return QMM_OP_RMS_NORM_MUL;
+    if (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU && qmm_op_supported(QMM_OP_SILU_MUL, &a, &b, nullptr, &d))
+        return QMM_OP_SILU_MUL;
+    return 0;
+}
+
 // ----------------------------------------------------------------------------------------------- backend (stream)
 
 const char * backend_get_name(ggml_backend_t backend) { return ((mi355x_backend_ctx *) backend->context)->name.c_str(); }
@@ -516,6 +616,36 @@ void backend_synchronize(ggml_backend_t backend) {
 
 enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
+    // fusion candidates: first nodes of (RMS_NORM | SILU) -> MUL pairs whose result nobody else reads.  One pass collects the
+    // candidates, one pass over all operands strikes those that have a second reader.
+    std::vector<const ggml_tensor *> & cand = ctx->fuse_cand;
+    cand.clear();
+    if (!GGML_MI355X_FUSE_OFF()) {
+        for (int i = 0; i + 1 < cgraph->n_nodes; ++i) {
+            const ggml_tensor * n0 = cgraph->nodes[i];
+            if ((n0->op == GGML_OP_RMS_NORM || n0->op == GGML_OP_UNARY) && cgraph->nodes[i + 1]->op == GGML_OP_MUL) cand.push_back(n0);
+        }
+        if (!cand.empty()) {
+            std::sort(cand.begin(), cand.end());
+            std::vector<int> & uses = ctx->fuse_uses;
+            uses.assign(cand.size(), 0);
+            for (int i = 0; i < cgraph->n_nodes; ++i) {
+                const ggml_tensor * n = cgraph->nodes[i];
+                for (int j = 0; j < GGML_MAX_SRC && n->src[j]; ++j) {
+                    auto it = std::lower_bound(cand.begin(), cand.end(), n->src[j]);
+                    if (it != cand.end() && *it == n->src[j]) ++uses[it - cand.begin()];
+                }
+                if (n->view_src) {
+                    auto it = std::lower_bound(cand.begin(), cand.end(), (const ggml_tensor *) n->view_src);
+                    if (it != cand.end() && *it == n->view_src) ++uses[it - cand.begin()];
+                }
+            }
+        }
+    }
+    auto single_use = [&](const ggml_tensor * t) {
+        auto it = std::lower_bound(cand.begin(), cand.end(), t);
+        return it != cand.end() && *it == t && ctx->fuse_uses[it - cand.begin()] == 1;
+    };
     for (int i = 0; i < cgraph->n_nodes;) {
         struct ggml_tensor * node = cgraph->nodes[i];
         if (ggml_is_empty(node) || node->op == GGML_OP_NONE || node->op == GGML_OP_RESHAPE || node->op == GGML_OP_VIEW ||
@@ -525,7 +655,24 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         }
         enum ggml_status st;
         int consumed = 1;
-        if (node->op == GGML_OP_MUL_MAT) {
+        const int gop = glue_op(node);
+        if (gop) {
+            const ggml_tensor * other = nullptr;
+            int fop = 0;
+            if (i + 1 < cgraph->n_nodes && (node->op == GGML_OP_RMS_NORM || node->op == GGML_OP_UNARY) && single_use(node))
+                fop = fused_pair(node, cgraph->nodes[i + 1], &other);
+            if (fop) {
+                ggml_tensor * out = cgraph->nodes[i + 1];
+                ggml_tensor tmp = *out;                                              // dst of the pair, carrying the first node's op_params (eps)
+                memcpy(tmp.op_params, node->op_params, sizeof(tmp.op_params));
+                st = compute_glue(ctx, &tmp, fop, node->src[0], other, nullptr);
+                consumed = 2;
+            } else if (gop == QMM_OP_CPY) {
+                st = compute_glue(ctx, node, gop, node->src[0], nullptr, nullptr);
+            } else {
+                st = compute_glue(ctx, node, gop, node->src[0], node->src[1], node->src[2]);
+            }
+        } else if (node->op == GGML_OP_MUL_MAT) {
             st = compute_mul_mat(ctx, cgraph->nodes + i, cgraph->n_nodes - i, &consumed);
         } else if (node->op == GGML_OP_MUL_MAT_ID) {
             st = compute_mul_mat_id(ctx, cgraph->nodes + i, cgraph->n_nodes - i, &consumed);
@@ -607,9 +754,9 @@ bool dev_supports_op(ggml_backend_dev_t, const struct ggml_tensor * op) {
     switch (op->op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
             return true;
-        case GGML_OP_MUL_MAT:    return supports_mul_mat(op);
+        case GGML_OP_MUL_MAT:    return glue_op(op) ? supports_glue(op) : supports_mul_mat(op);
         case GGML_OP_MUL_MAT_ID: return supports_mul_mat_id(op);
-        default: return false;
+        default: return supports_glue(op);
     }
 }
 bool dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {

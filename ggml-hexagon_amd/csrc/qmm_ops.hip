@@ -1,0 +1,714 @@
+// qmm_ops.hip — the per-layer glue ops around the quantized MUL_MAT path (include/ggml_mi355x_ops.h).
+// gfx950 only, no CPU path.  Every kernel is HBM-bound elementwise / row work except the small F16 attention matmuls,
+// which run on v_mfma_f32_32x32x16_f16.  Semantics follow the ggml CPU backend; each kernel cites the function it restates.
+// Parity: the reference's tests/test-backend-ops.cpp (built unmodified into oracle/_ref) against the CPU backend.
+
+#include "qmm_host.h"
+#include "../../include/ggml_mi355x_ops.h"
+#include "qmm_device.cuh"
+
+#include <hip/hip_fp16.h>
+#include <cmath>
+
+using namespace qmm;
+
+namespace {
+
+enum : int { G_F32 = 0, G_F16 = 1, G_I32 = 26 };
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float    f32x16v __attribute__((ext_vector_type(16)));
+
+struct Shape {           // extents and byte strides of one operand
+    int64_t ne[4];
+    int64_t nb[4];
+};
+Shape shape_of(const qmm_tensor * t) {
+    Shape s;
+    for (int i = 0; i < 4; ++i) { s.ne[i] = t->ne[i]; s.nb[i] = t->nb[i]; }
+    return s;
+}
+int64_t nelements(const qmm_tensor * t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
+int64_t nrows(const qmm_tensor * t) { return t->ne[1] * t->ne[2] * t->ne[3]; }
+int     esize(int type) { return type == G_F32 || type == G_I32 ? 4 : type == G_F16 ? 2 : 0; }
+bool    same_shape(const qmm_tensor * a, const qmm_tensor * b) {
+    return a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3];
+}
+bool contiguous(const qmm_tensor * t) {
+    const int es = esize(t->type);
+    if (!es) return false;
+    int64_t nb = es;
+    for (int i = 0; i < 4; ++i) {
+        if (t->ne[i] != 1 && t->nb[i] != nb) return false;
+        nb *= t->ne[i];
+    }
+    return true;
+}
+// rows are dense runs of elements (nb[0] == element size); rows themselves may sit anywhere
+bool dense_rows(const qmm_tensor * t) { return esize(t->type) && (t->nb[0] == esize(t->type) || t->ne[0] == 1); }
+bool fits_u32(const qmm_tensor * t) { return nelements(t) < ((int64_t) 1 << 31); }
+bool aligned_to(const qmm_tensor * t, int a) {
+    return (uintptr_t) t->data % a == 0 && t->nb[1] % a == 0 && t->nb[2] % a == 0 && t->nb[3] % a == 0;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide reductions over 256 threads (4 waves) through 4 floats of LDS
+template <bool MAX> __device__ __forceinline__ float block_reduce(float v, float * red) {
+    v = MAX ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = MAX ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+// row index -> byte offset of the row in a (possibly broadcast) operand
+__device__ __forceinline__ void row_coords(uint32_t row, uint32_t ne1, uint32_t ne2, uint32_t & i1, uint32_t & i2, uint32_t & i3) {
+    i1 = row % ne1;
+    const uint32_t t = row / ne1;
+    i2 = t % ne2;
+    i3 = t / ne2;
+}
+
+// ------------------------------------------------------------------------------------------------ binary ops
+// ggml_compute_forward_add/sub/mul/div (ggml-cpu/binary-ops.cpp; the DSP copy of add: kernels/ggml-dsp.c:991-1066):
+// dst[i] = src0[i] op src1[i mod ne1x], src1 broadcast over every dimension it is smaller in.
+template <int OP> __device__ __forceinline__ float bin(float a, float b) {
+    return OP == QMM_OP_ADD ? a + b : OP == QMM_OP_SUB ? a - b : OP == QMM_OP_MUL ? a * b : a / b;
+}
+
+// one block per group of rows; vector path when every row is 16-byte aligned and src1 has full rows
+template <int OP, bool VEC>
+__global__ void __launch_bounds__(256)
+binary_kernel(const char * __restrict__ a, const char * __restrict__ b, char * __restrict__ d, const Shape sa, const Shape sb,
+              const Shape sd, const uint32_t rows) {
+    const uint32_t ne0 = (uint32_t) sd.ne[0];
+    const uint32_t per_row = VEC ? ne0 / 4 : ne0;
+    const uint32_t rpb = per_row >= 256 ? 1 : 256 / per_row;          // rows per block for short rows
+    const uint32_t tpr = per_row >= 256 ? 256 : per_row;              // threads per row
+    const uint32_t lr = threadIdx.x / tpr;
+    if (lr >= rpb) return;
+    const uint32_t row = blockIdx.x * rpb + lr;
+    if (row >= rows) return;
+    uint32_t i1, i2, i3;
+    row_coords(row, (uint32_t) sd.ne[1], (uint32_t) sd.ne[2], i1, i2, i3);
+    const char * pa = a + i1 * sa.nb[1] + i2 * sa.nb[2] + i3 * sa.nb[3];
+    const char * pb = b + (i1 % (uint32_t) sb.ne[1]) * sb.nb[1] + (i2 % (uint32_t) sb.ne[2]) * sb.nb[2] + (i3 % (uint32_t) sb.ne[3]) * sb.nb[3];
+    char *       pd = d + i1 * sd.nb[1] + i2 * sd.nb[2] + i3 * sd.nb[3];
+    for (uint32_t i = threadIdx.x % tpr; i < per_row; i += tpr) {
+        if (VEC) {
+            const float4 x = ((const float4 *) pa)[i], y = ((const float4 *) pb)[i];
+            ((float4 *) pd)[i] = make_float4(bin<OP>(x.x, y.x), bin<OP>(x.y, y.y), bin<OP>(x.z, y.z), bin<OP>(x.w, y.w));
+        } else {
+            const float y = *(const float *) (pb + (i % (uint32_t) sb.ne[0]) * sb.nb[0]);
+            ((float *) pd)[i] = bin<OP>(((const float *) pa)[i], y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ unary / scale
+template <int OP> __device__ __forceinline__ float una(float x, float p) {
+    switch (OP) {
+        case QMM_OP_SCALE:      return x * p;                                            // ggml_vec_scale_f32
+        case QMM_OP_SILU:       return x / (1.0f + expf(-x));                            // ggml_silu_f32 (ggml-cpu.c)
+        case QMM_OP_GELU:       return 0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x)));
+        case QMM_OP_GELU_QUICK: return x * (1.0f / (1.0f + expf(-1.702f * x)));
+        case QMM_OP_RELU:       return x > 0.0f ? x : 0.0f;
+        case QMM_OP_TANH:       return tanhf(x);
+        case QMM_OP_SIGMOID:    return 1.0f / (1.0f + expf(-x));
+        case QMM_OP_NEG:        return -x;
+        case QMM_OP_EXP:        return expf(x);
+        default:                return x;
+    }
+}
+// contiguous f32; MUL2: dst = f(a) * b (SwiGLU: silu(gate) * up, the two nodes build_ffn emits back to back)
+template <int OP, bool MUL2>
+__global__ void __launch_bounds__(256)
+unary_kernel(const float * __restrict__ a, const float * __restrict__ b, float * __restrict__ d, const uint32_t n, const float p) {
+    const uint32_t i4 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (i4 + 3 < n && (((uintptr_t) a | (uintptr_t) d | (uintptr_t) b) & 15) == 0) {
+        const float4 x = *(const float4 *) (a + i4);
+        float4 r = make_float4(una<OP>(x.x, p), una<OP>(x.y, p), una<OP>(x.z, p), una<OP>(x.w, p));
+        if (MUL2) {
+            const float4 y = *(const float4 *) (b + i4);
+            r.x *= y.x; r.y *= y.y; r.z *= y.z; r.w *= y.w;
+        }
+        *(float4 *) (d + i4) = r;
+    } else {
+        for (uint32_t i = i4; i < n && i < i4 + 4; ++i) d[i] = una<OP>(a[i], p) * (MUL2 ? b[i] : 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ RMS_NORM
+// ggml_compute_forward_rms_norm_f32 (ggml-cpu.c:6254-6300): mean of squares over the row, y = x / sqrt(mean + eps).
+// One block per row; the row stays in registers (<= 8 values per thread) or is re-read from L2.
+// MUL: y *= w[i0] — the norm weight ggml_mul of build_norm, fused when the plugin sees the pair.
+template <bool MUL>
+__global__ void __launch_bounds__(256)
+rms_norm_kernel(const char * __restrict__ x, const float * __restrict__ w, char * __restrict__ y, const Shape sx, const Shape sy, const float eps) {
+    __shared__ float red[4];
+    uint32_t i1, i2, i3;
+    row_coords(blockIdx.x, (uint32_t) sx.ne[1], (uint32_t) sx.ne[2], i1, i2, i3);
+    const float * px = (const float *) (x + i1 * sx.nb[1] + i2 * sx.nb[2] + i3 * sx.nb[3]);
+    float *       py = (float *) (y + i1 * sy.nb[1] + i2 * sy.nb[2] + i3 * sy.nb[3]);
+    const uint32_t n = (uint32_t) sx.ne[0];
+    float keep[8];
+    float sum = 0.0f;
+    const bool in_regs = n <= 256 * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t i = threadIdx.x + j * 256;
+        keep[j] = in_regs && i < n ? px[i] : 0.0f;
+        sum += keep[j] * keep[j];
+    }
+    if (!in_regs)
+        for (uint32_t i = threadIdx.x; i < n; i += 256) sum += px[i] * px[i];
+    sum = block_reduce<false>(sum, red);
+    const float scale = 1.0f / sqrtf(sum / (float) n + eps);
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = threadIdx.x + j * 256;
+            if (i < n) py[i] = MUL ? keep[j] * scale * w[i] : keep[j] * scale;
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < n; i += 256) py[i] = MUL ? px[i] * scale * w[i] : px[i] * scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ SOFT_MAX
+// ggml_compute_forward_soft_max_f32 (ggml-cpu.c:8261-8352): v = x*scale + slope(head)*mask[row % ne01]; softmax over the row.
+// One block per row.  Rows up to 8192 values are staged in LDS; longer rows use dst as the staging area.
+template <bool MASK_F16>
+__global__ void __launch_bounds__(256)
+soft_max_kernel(const float * __restrict__ x, const void * __restrict__ mask, float * __restrict__ y, const uint32_t nc, const uint32_t ne01,
+                const uint32_t ne02, const float scale, const float max_bias, const float m0, const float m1, const uint32_t n_head_log2) {
+    extern __shared__ float stage[];
+    __shared__ float red[4];
+    const uint32_t row = blockIdx.x;
+    const uint32_t h = (row / ne01) % ne02;
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+    const float * px = x + (size_t) row * nc;
+    float *       py = y + (size_t) row * nc;
+    const bool in_lds = nc <= 8192;
+    float * v = in_lds ? stage : py;
+    const size_t moff = (size_t) (row % ne01) * nc;
+    float mx = -INFINITY;
+    for (uint32_t i = threadIdx.x; i < nc; i += 256) {
+        float t = px[i] * scale;
+        if (mask) t += slope * (MASK_F16 ? __half2float(((const __half *) mask)[moff + i]) : ((const float *) mask)[moff + i]);
+        v[i] = t;
+        mx = fmaxf(mx, t);
+    }
+    mx = block_reduce<true>(mx, red);
+    float sum = 0.0f;
+    for (uint32_t i = threadIdx.x; i < nc; i += 256) {
+        const float e = expf(v[i] - mx);          // a fully masked row (-inf everywhere) gives NaN on the CPU too
+        v[i] = e;
+        sum += e;
+    }
+    sum = block_reduce<false>(sum, red);
+    const float inv = 1.0f / sum;
+    for (uint32_t i = threadIdx.x; i < nc; i += 256) py[i] = v[i] * inv;
+}
+
+// ------------------------------------------------------------------------------------------------ ROPE
+// ggml_compute_forward_rope_f32 (ggml-cpu.c:8708-8893) with rope_yarn / ggml_rope_cache_init (:8610-8648): modes "normal"
+// (pairs (2p, 2p+1)) and NEOX (pairs (p, p + n_dims/2)); channels >= n_dims are copied.  theta is built by the same
+// repeated f32 multiply as the CPU cache (theta *= theta_scale), so it carries the same rounding.
+struct RopeParams {
+    int   n_dims, neox;
+    float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
+};
+__global__ void __launch_bounds__(256)
+rope_kernel(const char * __restrict__ x, const int32_t * __restrict__ pos, const float * __restrict__ ff, char * __restrict__ y,
+            const Shape sx, const Shape sy, const RopeParams rp, const uint32_t total_pairs) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid >= total_pairs) return;
+    const uint32_t half = (uint32_t) sx.ne[0] / 2;
+    const uint32_t p = gid % half;
+    uint32_t i1, i2, i3;
+    row_coords(gid / half, (uint32_t) sx.ne[1], (uint32_t) sx.ne[2], i1, i2, i3);
+    const float * px = (const float *) (x + i1 * sx.nb[1] + i2 * sx.nb[2] + i3 * sx.nb[3]);
+    float *       py = (float *) (y + i1 * sy.nb[1] + i2 * sy.nb[2] + i3 * sy.nb[3]);
+    const uint32_t i0 = 2 * p;
+    if (i0 >= (uint32_t) rp.n_dims) {             // pass-through channels
+        py[i0] = px[i0];
+        py[i0 + 1] = px[i0 + 1];
+        return;
+    }
+    float theta = (float) pos[i2];
+    for (uint32_t k = 0; k < p; ++k) theta *= rp.theta_scale;
+    const float theta_extrap = theta / (ff ? ff[p] : 1.0f);
+    const float theta_interp = rp.freq_scale * theta_extrap;
+    float th = theta_interp, mscale = rp.attn_factor;
+    if (rp.ext_factor != 0.0f) {
+        const float yv = ((float) (i0 / 2) - rp.corr0) / fmaxf(0.001f, rp.corr1 - rp.corr0);
+        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, yv))) * rp.ext_factor;
+        th = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / rp.freq_scale);
+    }
+    const float c = cosf(th) * mscale, s = sinf(th) * mscale;
+    const uint32_t ia = rp.neox ? p : i0, ib = rp.neox ? p + rp.n_dims / 2 : i0 + 1;
+    const float x0 = px[ia], x1 = px[ib];
+    py[ia] = x0 * c - x1 * s;
+    py[ib] = x0 * s + x1 * c;
+}
+
+// ------------------------------------------------------------------------------------------------ CPY / CONT / DUP
+// ggml_compute_forward_dup (ggml-cpu.c): element i of src (in src's index order) goes to element i of dst (in dst's
+// index order); shapes may differ, element counts agree.  F32 / F16 either side.
+template <typename T> __device__ __forceinline__ float ld_as_f32(const char * p);
+template <> __device__ __forceinline__ float ld_as_f32<float>(const char * p) { return *(const float *) p; }
+template <> __device__ __forceinline__ float ld_as_f32<__half>(const char * p) { return __half2float(*(const __half *) p); }
+template <typename T> __device__ __forceinline__ void st_from_f32(char * p, float v);
+template <> __device__ __forceinline__ void st_from_f32<float>(char * p, float v) { *(float *) p = v; }
+template <> __device__ __forceinline__ void st_from_f32<__half>(char * p, float v) { *(__half *) p = __float2half(v); }
+
+__device__ __forceinline__ size_t elem_offset(uint32_t i, const Shape & s) {
+    const uint32_t i0 = i % (uint32_t) s.ne[0];
+    uint32_t t = i / (uint32_t) s.ne[0];
+    const uint32_t i1 = t % (uint32_t) s.ne[1];
+    t /= (uint32_t) s.ne[1];
+    const uint32_t i2 = t % (uint32_t) s.ne[2], i3 = t / (uint32_t) s.ne[2];
+    return (size_t) i0 * s.nb[0] + (size_t) i1 * s.nb[1] + (size_t) i2 * s.nb[2] + (size_t) i3 * s.nb[3];
+}
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256)
+cpy_kernel(const char * __restrict__ x, char * __restrict__ y, const Shape sx, const Shape sy, const uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    st_from_f32<TD>(y + elem_offset(i, sy), ld_as_f32<TS>(x + elem_offset(i, sx)));
+}
+// 2-D transpose through LDS for the case the scalar kernel does worst: src is walked along its dim 1 (stride one element)
+// while dst rows are dense — the V-cache store of build_attn (v_cur^T [n_tokens, n_embd] -> rows of the transposed cache).
+// src element (i0, i1) at x + i0*sx0 + i1*sx1 with sx1 == sizeof(TS); dst element at y + i0*sizeof(TD) + i1*sy1.
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256)
+cpy_transpose_kernel(const char * __restrict__ x, char * __restrict__ y, const uint32_t ne0, const uint32_t ne1, const int64_t sx0,
+                     const int64_t sy1) {
+    __shared__ float tile[32][33];
+    const uint32_t b0 = blockIdx.x * 32, b1 = blockIdx.y * 32;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i0 = b0 + ty + j * 8, i1 = b1 + tx;                 // consecutive threads walk src's dense direction
+        if (i0 < ne0 && i1 < ne1) tile[ty + j * 8][tx] = ld_as_f32<TS>(x + (size_t) i0 * sx0 + (size_t) i1 * sizeof(TS));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i0 = b0 + tx, i1 = b1 + ty + j * 8;                 // ... and dst's dense direction
+        if (i0 < ne0 && i1 < ne1) st_from_f32<TD>(y + (size_t) i0 * sizeof(TD) + (size_t) i1 * sy1, tile[tx][ty + j * 8]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GET_ROWS
+// ggml_compute_forward_get_rows (ggml-cpu.c): dst[:, i10, i11, i12] = row src1[i10, i11, i12] of src0[:, :, i11, i12] as f32.
+template <typename TS>
+__global__ void __launch_bounds__(256)
+get_rows_kernel(const char * __restrict__ x, const char * __restrict__ ids, char * __restrict__ y, const Shape sx, const Shape si, const Shape sy) {
+    uint32_t i10, i11, i12;
+    row_coords(blockIdx.x, (uint32_t) si.ne[0], (uint32_t) si.ne[1], i10, i11, i12);
+    const int32_t r = *(const int32_t *) (ids + i10 * si.nb[0] + i11 * si.nb[1] + i12 * si.nb[2]);
+    if (r < 0 || r >= sx.ne[1]) return;                      // the CPU asserts; leave the row untouched
+    const char * px = x + (size_t) r * sx.nb[1] + i11 * sx.nb[2] + i12 * sx.nb[3];
+    float *      py = (float *) (y + i10 * sy.nb[1] + i11 * sy.nb[2] + i12 * sy.nb[3]);
+    for (uint32_t i = threadIdx.x; i < (uint32_t) sx.ne[0]; i += 256) py[i] = ld_as_f32<TS>(px + (size_t) i * sizeof(TS));
+}
+// quantized rows: one unit per thread, the bit-exact unpack of qmm_device.cuh
+template <int T>
+__global__ void __launch_bounds__(256)
+get_rows_q_kernel(const uint8_t * __restrict__ x, const char * __restrict__ ids, char * __restrict__ y, const Shape sx, const Shape si, const Shape sy) {
+    uint32_t i10, i11, i12;
+    row_coords(blockIdx.x, (uint32_t) si.ne[0], (uint32_t) si.ne[1], i10, i11, i12);
+    const int32_t r = *(const int32_t *) (ids + i10 * si.nb[0] + i11 * si.nb[1] + i12 * si.nb[2]);
+    if (r < 0 || r >= sx.ne[1]) return;
+    const uint8_t * px = x + (size_t) r * sx.nb[1] + i11 * sx.nb[2] + i12 * sx.nb[3];
+    float *         py = (float *) (y + i10 * sy.nb[1] + i11 * sy.nb[2] + i12 * sy.nb[3]);
+    const int units = (int) (sx.ne[0] / Traits<T>::UNIT_W);
+    for (int u = threadIdx.x; u < units; u += 256) {
+        Unit<T> un;
+        un.load(px, u);
+        float out[Traits<T>::UNIT_W];
+        un.to_f32(u, out);
+#pragma unroll
+        for (int rr = 0; rr < Unit<T>::RUNS; ++rr) {
+            float * o = py + Unit<T>::k_run(u, rr);
+#pragma unroll
+            for (int e = 0; e < Unit<T>::RUN_LEN; ++e) o[e] = out[rr * Unit<T>::RUN_LEN + e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ MUL_MAT, F16 / F32 src0
+// ggml_compute_forward_mul_mat with a non-quantized src0 (ggml-cpu.c:6745-6937): the KQ and KQV products of
+// build_attn_mha (src/llama-graph.cpp:1126-1213), whose src0 is a strided view of the F16 KV cache, and small F32 matrices
+// (the MoE router).  dst[i13][i12][n][m] = sum_k src0[i13/r3][i12/r2][m][k] * src1[i13][i12][n][k].
+//
+// F16: as on the CPU (vec_dot_type of F16 is F16: src1 is rounded to f16, products accumulate in f32).  A workgroup of 4 waves
+// owns 64 src0 rows x 64 src1 rows; both operands go through LDS as f16 in 32-deep K-steps and each wave drives
+// v_mfma_f32_32x32x16_f16 with tokens on the MFMA row index and src0 rows on the lane index, so a lane's 16 results are
+// 16 tokens of ONE dst column and every store instruction writes 128 contiguous bytes per half-wave.
+struct MmArgs {
+    const char * a;  const char * b;  char * d;
+    int64_t a_nb1, a_nb2, a_nb3, b_nb1, b_nb2, b_nb3, d_nb1, d_nb2, d_nb3;
+    int32_t M, N, K, ne12, r2, r3;
+};
+constexpr int MM_T = 64, MM_BK = 32, MM_LD = MM_BK + 8;      // LDS row pitch 80 B: 16-byte reads of 32 rows spread over all banks
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+mul_mat_f16_kernel(const MmArgs g) {
+    __shared__ __attribute__((aligned(16))) _Float16 sa[MM_T * MM_LD];        // src0 rows (weights side)
+    __shared__ __attribute__((aligned(16))) _Float16 sb[MM_T * MM_LD];        // src1 rows (tokens), rounded to f16
+    const int i12 = blockIdx.z % g.ne12, i13 = blockIdx.z / g.ne12;
+    const char * pa = g.a + (int64_t) (i12 / g.r2) * g.a_nb2 + (int64_t) (i13 / g.r3) * g.a_nb3;
+    const char * pb = g.b + (int64_t) i12 * g.b_nb2 + (int64_t) i13 * g.b_nb3;
+    char *       pd = g.d + (int64_t) i12 * g.d_nb2 + (int64_t) i13 * g.d_nb3;
+    const int m0 = blockIdx.x * MM_T, n0 = blockIdx.y * MM_T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    const int lr = tid >> 2, lk = (tid & 3) * 8;                               // staging: row lr, 8 consecutive k from lk
+    f32x16v acc = {0};
+    for (int k0 = 0; k0 < g.K; k0 += MM_BK) {
+        h16x8 va = {0}, vb = {0};
+        const int k = k0 + lk;
+        if (m0 + lr < g.M) {
+            const char * p = pa + (int64_t) (m0 + lr) * g.a_nb1 + (int64_t) k * 2;
+            if (VEC && k + 8 <= g.K) {
+                va = *(const h16x8 *) p;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (k + e < g.K) va[e] = ((const _Float16 *) p)[e];
+            }
+        }
+        if (n0 + lr < g.N) {
+            const float * p = (const float *) (pb + (int64_t) (n0 + lr) * g.b_nb1) + k;
+            if (VEC && k + 8 <= g.K) {
+                const float4 x = ((const float4 *) p)[0], y = ((const float4 *) p)[1];
+                vb = h16x8{ (_Float16) x.x, (_Float16) x.y, (_Float16) x.z, (_Float16) x.w, (_Float16) y.x, (_Float16) y.y, (_Float16) y.z, (_Float16) y.w };
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (k + e < g.K) vb[e] = (_Float16) p[e];
+            }
+        }
+        __syncthreads();                                                        // previous K-step's fragment reads are done
+        *(h16x8 *) &sa[lr * MM_LD + lk] = va;
+        *(h16x8 *) &sb[lr * MM_LD + lk] = vb;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < MM_BK; kk += 16) {
+            const h16x8 fa = *(const h16x8 *) &sb[(wn + (lane & 31)) * MM_LD + kk + (lane >> 5) * 8];     // tokens: MFMA rows
+            const h16x8 fb = *(const h16x8 *) &sa[(wm + (lane & 31)) * MM_LD + kk + (lane >> 5) * 8];     // src0 rows: MFMA columns
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0);
+        }
+    }
+    const int m = m0 + wm + (lane & 31);
+    if (m < g.M) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            if (n < g.N) *(float *) (pd + (int64_t) n * g.d_nb1 + (int64_t) m * 4) = acc[r];
+        }
+    }
+}
+
+// F32 src0 (small matrices such as the MoE router ffn_gate_inp): one wave per dst element, f32 FMA, lanes stride K.
+template <typename TA>
+__global__ void __launch_bounds__(256)
+mul_mat_dot_kernel(const MmArgs g) {
+    const int i12 = blockIdx.z % g.ne12, i13 = blockIdx.z / g.ne12;
+    const int64_t e = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= (int64_t) g.M * g.N) return;
+    const int m = (int) (e % g.M), n = (int) (e / g.M), lane = threadIdx.x & 63;
+    const char *  pa = g.a + (int64_t) (i12 / g.r2) * g.a_nb2 + (int64_t) (i13 / g.r3) * g.a_nb3 + (int64_t) m * g.a_nb1;
+    const float * pb = (const float *) (g.b + (int64_t) i12 * g.b_nb2 + (int64_t) i13 * g.b_nb3 + (int64_t) n * g.b_nb1);
+    float s = 0.0f;
+    for (int k = lane; k < g.K; k += 64) s += ld_as_f32<TA>(pa + (int64_t) k * sizeof(TA)) * pb[k];
+    s = wave_sum(s);
+    if (lane == 0) *(float *) (g.d + (int64_t) i12 * g.d_nb2 + (int64_t) i13 * g.d_nb3 + (int64_t) n * g.d_nb1 + (int64_t) m * 4) = s;
+}
+
+// ------------------------------------------------------------------------------------------------ support predicates
+
+bool is_binary(int op) { return op >= QMM_OP_ADD && op <= QMM_OP_DIV; }
+bool is_unary(int op) { return op >= QMM_OP_SCALE && op <= QMM_OP_EXP; }
+bool quant_type(int t) { return t == T_Q4_0 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K; }
+int  quant_blck(int t) { return t == T_Q4_0 || t == T_Q8_0 ? 32 : 256; }
+
+bool sup_binary(const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * d) {
+    if (!a || !b || !d || a->type != G_F32 || b->type != G_F32 || d->type != G_F32) return false;
+    if (!same_shape(a, d) || !dense_rows(a) || !dense_rows(d) || !fits_u32(d) || nelements(d) == 0) return false;
+    for (int i = 0; i < 4; ++i) if (b->ne[i] <= 0 || d->ne[i] % b->ne[i]) return false;       // ggml_can_repeat(b, a)
+    return a->nb[1] % 4 == 0 && a->nb[2] % 4 == 0 && a->nb[3] % 4 == 0 && b->nb[0] % 4 == 0 && b->nb[1] % 4 == 0 && b->nb[2] % 4 == 0 &&
+           b->nb[3] % 4 == 0;
+}
+bool sup_unary(const qmm_tensor * a, const qmm_tensor * d) {
+    return a && d && a->type == G_F32 && d->type == G_F32 && same_shape(a, d) && contiguous(a) && contiguous(d) && fits_u32(d);
+}
+bool sup_rms_norm(const qmm_tensor * a, const qmm_tensor * d) {
+    return a && d && a->type == G_F32 && d->type == G_F32 && same_shape(a, d) && dense_rows(a) && dense_rows(d) && fits_u32(d) &&
+           nelements(d) > 0;
+}
+bool sup_rope(const qmm_tensor * a, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * d) {
+    if (!a || !pos || !d || a->type != G_F32 || d->type != G_F32 || pos->type != G_I32 || !same_shape(a, d)) return false;
+    if (!dense_rows(a) || !dense_rows(d) || !contiguous(pos) || !fits_u32(d) || nelements(d) == 0 || a->ne[0] % 2) return false;
+    const int n_dims = d->op_params[1], mode = d->op_params[2];
+    if (mode != 0 && mode != 2) return false;                                     // normal or NEOX; no M-RoPE / vision
+    if (n_dims <= 0 || n_dims % 2 || n_dims > a->ne[0] || pos->ne[0] != a->ne[2]) return false;
+    if (ff && (ff->type != G_F32 || ff->ne[0] < n_dims / 2 || !contiguous(ff))) return false;
+    return true;
+}
+bool sup_soft_max(const qmm_tensor * a, const qmm_tensor * mask, const qmm_tensor * d) {
+    if (!a || !d || a->type != G_F32 || d->type != G_F32 || !same_shape(a, d) || !contiguous(a) || !contiguous(d)) return false;
+    if (nelements(d) == 0 || nrows(d) >= ((int64_t) 1 << 31)) return false;
+    if (mask) {
+        if (mask->type != G_F32 && mask->type != G_F16) return false;
+        if (!contiguous(mask) || mask->ne[0] != a->ne[0] || mask->ne[1] < a->ne[1] || mask->ne[2] != 1 || mask->ne[3] != 1) return false;
+    }
+    return true;
+}
+bool sup_cpy(const qmm_tensor * a, const qmm_tensor * d) {
+    if (!a || !d || !esize(a->type) || !esize(d->type) || a->type == G_I32 || d->type == G_I32) return false;
+    return nelements(a) == nelements(d) && fits_u32(a) && a->nb[0] % esize(a->type) == 0 && d->nb[0] % esize(d->type) == 0;
+}
+bool sup_get_rows(const qmm_tensor * a, const qmm_tensor * ids, const qmm_tensor * d) {
+    if (!a || !ids || !d || ids->type != G_I32 || d->type != G_F32 || !dense_rows(d) || nelements(d) == 0) return false;
+    if (d->ne[0] != a->ne[0] || d->ne[1] != ids->ne[0] || d->ne[2] != ids->ne[1] || d->ne[3] != ids->ne[2] || ids->ne[3] != 1) return false;
+    if (a->ne[2] != ids->ne[1] || a->ne[3] != ids->ne[2] || nrows(d) >= ((int64_t) 1 << 31)) return false;
+    if (quant_type(a->type)) return a->ne[0] % quant_blck(a->type) == 0 && a->nb[1] % 2 == 0;
+    return (a->type == G_F32 || a->type == G_F16) && dense_rows(a);
+}
+bool sup_mul_mat_f(const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * d) {
+    if (!a || !b || !d || (a->type != G_F16 && a->type != G_F32) || b->type != G_F32 || d->type != G_F32) return false;
+    if (a->ne[0] != b->ne[0] || d->ne[0] != a->ne[1] || d->ne[1] != b->ne[1] || d->ne[2] != b->ne[2] || d->ne[3] != b->ne[3]) return false;
+    if (a->ne[2] <= 0 || a->ne[3] <= 0 || b->ne[2] % a->ne[2] || b->ne[3] % a->ne[3] || nelements(d) == 0 || a->ne[0] == 0) return false;
+    if (a->nb[0] != esize(a->type) || b->nb[0] != 4 || d->nb[0] != 4) return false;         // K dense in both operands
+    if (b->ne[2] * b->ne[3] > 65535 || a->ne[1] >= ((int64_t) 1 << 30) || b->ne[1] >= ((int64_t) 1 << 22)) return false;
+    return a->nb[1] % esize(a->type) == 0 && a->nb[2] % esize(a->type) == 0 && a->nb[3] % esize(a->type) == 0 && b->nb[1] % 4 == 0 &&
+           b->nb[2] % 4 == 0 && b->nb[3] % 4 == 0 && d->nb[1] % 4 == 0 && d->nb[2] % 4 == 0 && d->nb[3] % 4 == 0;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+
+template <int OP>
+int launch_binary(hipStream_t st, const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * d) {
+    const uint32_t rows = (uint32_t) nrows(d);
+    const bool vec = d->ne[0] % 4 == 0 && b->ne[0] == d->ne[0] && b->nb[0] == 4 && aligned_to(a, 16) && aligned_to(b, 16) && aligned_to(d, 16);
+    const uint32_t per_row = (uint32_t) (vec ? d->ne[0] / 4 : d->ne[0]);
+    const uint32_t rpb = per_row >= 256 ? 1 : 256 / per_row;
+    const dim3 grid((rows + rpb - 1) / rpb);
+    if (vec) hipLaunchKernelGGL((binary_kernel<OP, true>), grid, dim3(256), 0, st, (const char *) a->data, (const char *) b->data, (char *) d->data,
+                                shape_of(a), shape_of(b), shape_of(d), rows);
+    else     hipLaunchKernelGGL((binary_kernel<OP, false>), grid, dim3(256), 0, st, (const char *) a->data, (const char *) b->data, (char *) d->data,
+                                shape_of(a), shape_of(b), shape_of(d), rows);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+template <int OP, bool MUL2>
+int launch_unary(hipStream_t st, const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * d, float p) {
+    const uint32_t n = (uint32_t) nelements(d);
+    if (n == 0) return QMM_OK;
+    hipLaunchKernelGGL((unary_kernel<OP, MUL2>), dim3((n + 1023) / 1024), dim3(256), 0, st, (const float *) a->data,
+                       b ? (const float *) b->data : nullptr, (float *) d->data, n, p);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+template <typename TS, typename TD>
+int launch_cpy_t(hipStream_t st, const qmm_tensor * a, const qmm_tensor * d) {
+    const uint32_t n = (uint32_t) nelements(a);
+    // transposed source into dense rows (the V-cache store): 2-D, same extents, src dense along dim 1, dst dense along dim 0
+    if (a->ne[2] == 1 && a->ne[3] == 1 && d->ne[2] == 1 && d->ne[3] == 1 && a->ne[0] == d->ne[0] && a->ne[1] == d->ne[1] &&
+        a->nb[1] == (int64_t) sizeof(TS) && d->nb[0] == (int64_t) sizeof(TD) && a->ne[0] >= 32 && a->ne[1] >= 8) {
+        hipLaunchKernelGGL((cpy_transpose_kernel<TS, TD>), dim3((unsigned) ((a->ne[0] + 31) / 32), (unsigned) ((a->ne[1] + 31) / 32)), dim3(256), 0, st,
+                           (const char *) a->data, (char *) d->data, (uint32_t) a->ne[0], (uint32_t) a->ne[1], a->nb[0], d->nb[1]);
+    } else {
+        hipLaunchKernelGGL((cpy_kernel<TS, TD>), dim3((n + 255) / 256), dim3(256), 0, st, (const char *) a->data, (char *) d->data, shape_of(a),
+                           shape_of(d), n);
+    }
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+int launch_cpy(hipStream_t st, const qmm_tensor * a, const qmm_tensor * d) {
+    if (nelements(a) == 0) return QMM_OK;
+    if (a->type == d->type && contiguous(a) && contiguous(d)) {
+        if (a->data != d->data) HIP_TRY(hipMemcpyAsync(d->data, a->data, (size_t) nelements(a) * esize(a->type), hipMemcpyDeviceToDevice, st));
+        return QMM_OK;
+    }
+    if (a->type == G_F32 && d->type == G_F32) return launch_cpy_t<float, float>(st, a, d);
+    if (a->type == G_F32 && d->type == G_F16) return launch_cpy_t<float, __half>(st, a, d);
+    if (a->type == G_F16 && d->type == G_F16) return launch_cpy_t<__half, __half>(st, a, d);
+    return launch_cpy_t<__half, float>(st, a, d);
+}
+
+template <int T>
+int launch_get_rows_q(hipStream_t st, const qmm_tensor * a, const qmm_tensor * ids, const qmm_tensor * d) {
+    hipLaunchKernelGGL((get_rows_q_kernel<T>), dim3((unsigned) nrows(d)), dim3(256), 0, st, (const uint8_t *) a->data, (const char *) ids->data,
+                       (char *) d->data, shape_of(a), shape_of(ids), shape_of(d));
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+int launch_mul_mat_f(hipStream_t st, const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * d) {
+    MmArgs g;
+    g.a = (const char *) a->data;  g.b = (const char *) b->data;  g.d = (char *) d->data;
+    g.a_nb1 = a->nb[1]; g.a_nb2 = a->nb[2]; g.a_nb3 = a->nb[3];
+    g.b_nb1 = b->nb[1]; g.b_nb2 = b->nb[2]; g.b_nb3 = b->nb[3];
+    g.d_nb1 = d->nb[1]; g.d_nb2 = d->nb[2]; g.d_nb3 = d->nb[3];
+    g.M = (int32_t) a->ne[1]; g.N = (int32_t) b->ne[1]; g.K = (int32_t) a->ne[0];
+    g.ne12 = (int32_t) b->ne[2]; g.r2 = (int32_t) (b->ne[2] / a->ne[2]); g.r3 = (int32_t) (b->ne[3] / a->ne[3]);
+    const unsigned batch = (unsigned) (b->ne[2] * b->ne[3]);
+    if (a->type == G_F16) {
+        const dim3 grid((g.M + MM_T - 1) / MM_T, (g.N + MM_T - 1) / MM_T, batch);
+        const bool vec = aligned_to(a, 16) && aligned_to(b, 16);
+        if (vec) hipLaunchKernelGGL((mul_mat_f16_kernel<true>), grid, dim3(256), 0, st, g);
+        else     hipLaunchKernelGGL((mul_mat_f16_kernel<false>), grid, dim3(256), 0, st, g);
+    } else {
+        const int64_t e = (int64_t) g.M * g.N;
+        hipLaunchKernelGGL((mul_mat_dot_kernel<float>), dim3((unsigned) ((e + 3) / 4), 1, batch), dim3(256), 0, st, g);
+    }
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+float f32_param(const qmm_tensor * d, int i) {
+    float v;
+    memcpy(&v, &d->op_params[i], sizeof(float));
+    return v;
+}
+
+// ggml_rope_yarn_corr_dims (ggml.c:3738-3754)
+void rope_corr_dims(int n_dims, int n_ctx_orig, float freq_base, float beta_fast, float beta_slow, float dims[2]) {
+    auto corr_dim = [&](float n_rot) { return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(freq_base)); };
+    const float start = floorf(corr_dim(beta_fast)), end = ceilf(corr_dim(beta_slow));
+    dims[0] = start > 0 ? start : 0;
+    dims[1] = end < n_dims - 1 ? end : n_dims - 1;
+}
+
+} // namespace
+
+extern "C" {
+
+int qmm_op_supported(int op, const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * c, const qmm_tensor * d) {
+    if (is_binary(op)) return sup_binary(a, b, d);
+    if (is_unary(op)) return sup_unary(a, d);
+    switch (op) {
+        case QMM_OP_RMS_NORM:     return sup_rms_norm(a, d);
+        case QMM_OP_RMS_NORM_MUL: return sup_rms_norm(a, d) && b && b->type == G_F32 && contiguous(b) && b->ne[0] == a->ne[0] && nelements(b) == b->ne[0];
+        case QMM_OP_SILU_MUL:     return sup_unary(a, d) && b && sup_unary(b, d);
+        case QMM_OP_ROPE:         return sup_rope(a, b, c, d);
+        case QMM_OP_SOFT_MAX:     return sup_soft_max(a, b, d);
+        case QMM_OP_CPY:          return sup_cpy(a, d);
+        case QMM_OP_GET_ROWS:     return sup_get_rows(a, b, d);
+        case QMM_OP_MUL_MAT_F:    return sup_mul_mat_f(a, b, d);
+        default:                  return 0;
+    }
+}
+
+int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * c, const qmm_tensor * d, void * stream) {
+    if (!ctx || !d) return fail(QMM_EINVAL, "qmm_op_compute: NULL context or dst");
+    if (!qmm_op_supported(op, a, b, c, d)) return fail(QMM_EUNSUPPORTED, "qmm_op_compute: op %d with these types / shapes / strides is not implemented", op);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->s(stream);
+    switch (op) {
+        case QMM_OP_ADD: return launch_binary<QMM_OP_ADD>(st, a, b, d);
+        case QMM_OP_SUB: return launch_binary<QMM_OP_SUB>(st, a, b, d);
+        case QMM_OP_MUL: return launch_binary<QMM_OP_MUL>(st, a, b, d);
+        case QMM_OP_DIV: return launch_binary<QMM_OP_DIV>(st, a, b, d);
+        case QMM_OP_SCALE:      return launch_unary<QMM_OP_SCALE, false>(st, a, nullptr, d, f32_param(d, 0));
+        case QMM_OP_SILU:       return launch_unary<QMM_OP_SILU, false>(st, a, nullptr, d, 0);
+        case QMM_OP_GELU:       return launch_unary<QMM_OP_GELU, false>(st, a, nullptr, d, 0);
+        case QMM_OP_GELU_QUICK: return launch_unary<QMM_OP_GELU_QUICK, false>(st, a, nullptr, d, 0);
+        case QMM_OP_RELU:       return launch_unary<QMM_OP_RELU, false>(st, a, nullptr, d, 0);
+        case QMM_OP_TANH:       return launch_unary<QMM_OP_TANH, false>(st, a, nullptr, d, 0);
+        case QMM_OP_SIGMOID:    return launch_unary<QMM_OP_SIGMOID, false>(st, a, nullptr, d, 0);
+        case QMM_OP_NEG:        return launch_unary<QMM_OP_NEG, false>(st, a, nullptr, d, 0);
+        case QMM_OP_EXP:        return launch_unary<QMM_OP_EXP, false>(st, a, nullptr, d, 0);
+        case QMM_OP_SILU_MUL:   return launch_unary<QMM_OP_SILU, true>(st, a, b, d, 0);
+        case QMM_OP_RMS_NORM:
+        case QMM_OP_RMS_NORM_MUL: {
+            const float eps = f32_param(d, 0);
+            if (eps < 0.0f) return fail(QMM_EINVAL, "RMS_NORM: eps < 0");
+            const dim3 grid((unsigned) nrows(d));
+            if (op == QMM_OP_RMS_NORM_MUL)
+                hipLaunchKernelGGL((rms_norm_kernel<true>), grid, dim3(256), 0, st, (const char *) a->data, (const float *) b->data, (char *) d->data,
+                                   shape_of(a), shape_of(d), eps);
+            else
+                hipLaunchKernelGGL((rms_norm_kernel<false>), grid, dim3(256), 0, st, (const char *) a->data, (const float *) nullptr, (char *) d->data,
+                                   shape_of(a), shape_of(d), eps);
+            HIP_TRY(hipGetLastError());
+            return QMM_OK;
+        }
+        case QMM_OP_ROPE: {
+            RopeParams rp;
+            rp.n_dims = d->op_params[1];
+            rp.neox = (d->op_params[2] & 2) != 0;
+            const int n_ctx_orig = d->op_params[4];
+            const float freq_base = f32_param(d, 5), beta_fast = f32_param(d, 9), beta_slow = f32_param(d, 10);
+            rp.freq_scale = f32_param(d, 6);
+            rp.ext_factor = f32_param(d, 7);
+            rp.attn_factor = f32_param(d, 8);
+            rp.theta_scale = powf(freq_base, -2.0f / rp.n_dims);
+            float cd[2];
+            rope_corr_dims(rp.n_dims, n_ctx_orig, freq_base, beta_fast, beta_slow, cd);
+            rp.corr0 = cd[0];
+            rp.corr1 = cd[1];
+            const uint32_t pairs = (uint32_t) (nelements(d) / 2);
+            hipLaunchKernelGGL(rope_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, (const char *) a->data, (const int32_t *) b->data,
+                               c ? (const float *) c->data : nullptr, (char *) d->data, shape_of(a), shape_of(d), rp, pairs);
+            HIP_TRY(hipGetLastError());
+            return QMM_OK;
+        }
+        case QMM_OP_SOFT_MAX: {
+            const float scale = f32_param(d, 0), max_bias = f32_param(d, 1);
+            const uint32_t nc = (uint32_t) a->ne[0], ne01 = (uint32_t) a->ne[1], ne02 = (uint32_t) a->ne[2];
+            const uint32_t n_head_log2 = 1u << (uint32_t) floor(log2((double) ne02));
+            const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+            const size_t lds = nc <= 8192 ? (size_t) nc * 4 : 0;
+            const dim3 grid((unsigned) nrows(d));
+            if (b && b->type == G_F16)
+                hipLaunchKernelGGL((soft_max_kernel<true>), grid, dim3(256), lds, st, (const float *) a->data, (const void *) b->data, (float *) d->data,
+                                   nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
+            else
+                hipLaunchKernelGGL((soft_max_kernel<false>), grid, dim3(256), lds, st, (const float *) a->data, b ? (const void *) b->data : nullptr,
+                                   (float *) d->data, nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
+            HIP_TRY(hipGetLastError());
+            return QMM_OK;
+        }
+        case QMM_OP_CPY: return launch_cpy(st, a, d);
+        case QMM_OP_GET_ROWS: {
+            const dim3 grid((unsigned) nrows(d));
+            switch (a->type) {
+                case G_F32: hipLaunchKernelGGL((get_rows_kernel<float>), grid, dim3(256), 0, st, (const char *) a->data, (const char *) b->data,
+                                               (char *) d->data, shape_of(a), shape_of(b), shape_of(d)); break;
+                case G_F16: hipLaunchKernelGGL((get_rows_kernel<__half>), grid, dim3(256), 0, st, (const char *) a->data, (const char *) b->data,
+                                               (char *) d->data, shape_of(a), shape_of(b), shape_of(d)); break;
+                case T_Q4_0: return launch_get_rows_q<T_Q4_0>(st, a, b, d);
+                case T_Q8_0: return launch_get_rows_q<T_Q8_0>(st, a, b, d);
+                case T_Q4_K: return launch_get_rows_q<T_Q4_K>(st, a, b, d);
+                case T_Q5_K: return launch_get_rows_q<T_Q5_K>(st, a, b, d);
+                default:     return launch_get_rows_q<T_Q6_K>(st, a, b, d);
+            }
+            HIP_TRY(hipGetLastError());
+            return QMM_OK;
+        }
+        case QMM_OP_MUL_MAT_F: return launch_mul_mat_f(st, a, b, d);
+        default: return fail(QMM_EUNSUPPORTED, "qmm_op_compute: unknown op %d", op);
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,329 @@
+// llama_e2e.cpp — end-to-end check of the drop-in claim: the reference's own libllama (compiled unmodified into
+// oracle/_ref by oracle/Makefile) loads a synthetic-weight GGUF, picks up the MI355X backend module through
+// GGML_BACKEND_PATH and runs llama-bench's protocol on it.  Public llama.h / ggml.h / gguf.h API only.
+//
+//   llama-e2e write   --config NAME --gguf PATH              write the synthetic GGUF (SURVEY §8d "model level" recipe)
+//   llama-e2e bench   --gguf PATH [--ngl N] [-p 512] [-n 128] [-r 3] [-t T]
+//                         llama-bench's pp / tg test (examples/llama-bench/llama-bench.cpp:1428-1467 test_prompt / test_gen,
+//                         :1605-1642 warm-up + reps): one JSON line with tok/s
+//   llama-e2e compare --gguf PATH [-p 64] [-n 8] [-t T]      same tokens through the CPU backend (ngl 0) and the offloaded
+//                         model (ngl 99): NMSE of the logits of the last prompt token and of every generated step
+//
+// llama-bench itself is not built (it needs cmake-generated build-info.cpp); this file is ours and only restates its
+// measurement protocol.  The GGUF has tokenizer.ggml.model = "no_vocab" (src/llama-vocab.cpp:1373): llama-bench feeds
+// random token ids, so no tokenizer is needed.
+
+#include "ggml.h"
+#include "ggml-backend.h"
+#include "gguf.h"
+#include "llama.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct Config {
+    const char * name;
+    int n_layer, n_embd, n_ff, n_head, n_head_kv, n_vocab;
+    float rope_base;
+    const char * recipe;     // q4_0 | q4_k | q4_k_m
+    int n_expert, n_used;
+};
+static const Config CONFIGS[] = {
+    { "tiny-q4_k_m",        4, 1024,  2816,  8, 2,   4096,  10000.0f, "q4_k_m", 0, 0 },
+    { "tiny-q4_0",          2, 1024,  2816,  8, 8,   4096,  10000.0f, "q4_0",   0, 0 },
+    { "tiny-moe-q4_k_m",    2, 1024,  2816,  8, 2,   4096,  10000.0f, "q4_k_m", 8, 2 },
+    { "llama2-7b-q4_0",    32, 4096, 11008, 32, 32,  32000, 10000.0f, "q4_0",   0, 0 },
+    { "llama3-8b-q4_k_m",  32, 4096, 14336, 32, 8,  128256, 500000.0f, "q4_k_m", 0, 0 },
+    { "synth-7b-q4_k",     32, 4096, 11008, 32, 32,  32000, 10000.0f, "q4_k",   0, 0 },
+    { "mixtral-8x7b-q4_k_m", 32, 4096, 14336, 32, 8, 32000, 1000000.0f, "q4_k_m", 8, 2 },
+};
+
+static bool use_more_bits(int i, int n) { return i < n / 8 || i >= 7 * n / 8 || (i - n / 8) % 3 == 2; }   // src/llama-quant.cpp:129-131
+
+struct TensorSpec {
+    std::string name;
+    ggml_type   type;
+    int64_t     ne[3];
+    int         n_dims;
+};
+
+// per-tensor types of llama-quant.cpp's recipes (same table as ggml-hexagon_amd/workload.py)
+static std::vector<TensorSpec> tensor_list(const Config & c) {
+    std::vector<TensorSpec> ts;
+    const bool q40 = !strcmp(c.recipe, "q4_0"), q4k = !strcmp(c.recipe, "q4_k");
+    const ggml_type base = q40 ? GGML_TYPE_Q4_0 : GGML_TYPE_Q4_K;
+    const int64_t kv = (int64_t) c.n_embd / c.n_head * c.n_head_kv;
+    ts.push_back({ "token_embd.weight", base, { c.n_embd, c.n_vocab, 1 }, 2 });
+    ts.push_back({ "output_norm.weight", GGML_TYPE_F32, { c.n_embd, 1, 1 }, 1 });
+    ts.push_back({ "output.weight", q4k ? GGML_TYPE_Q4_K : GGML_TYPE_Q6_K, { c.n_embd, c.n_vocab, 1 }, 2 });
+    for (int i = 0; i < c.n_layer; ++i) {
+        ggml_type tq = base, tk = base, tv = base, to = base, tg = base, td = base;
+        if (!q40 && !q4k) {
+            const bool more = use_more_bits(i, c.n_layer);
+            tv = td = more ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K;
+            if (c.n_layer >= 80 && tv == GGML_TYPE_Q4_K) tv = GGML_TYPE_Q5_K;
+            if (c.n_expert == 8) { tk = tv = GGML_TYPE_Q8_0; to = GGML_TYPE_Q5_K; }
+        }
+        const std::string b = "blk." + std::to_string(i) + ".";
+        ts.push_back({ b + "attn_norm.weight", GGML_TYPE_F32, { c.n_embd, 1, 1 }, 1 });
+        ts.push_back({ b + "attn_q.weight", tq, { c.n_embd, c.n_embd, 1 }, 2 });
+        ts.push_back({ b + "attn_k.weight", tk, { c.n_embd, kv, 1 }, 2 });
+        ts.push_back({ b + "attn_v.weight", tv, { c.n_embd, kv, 1 }, 2 });
+        ts.push_back({ b + "attn_output.weight", to, { c.n_embd, c.n_embd, 1 }, 2 });
+        ts.push_back({ b + "ffn_norm.weight", GGML_TYPE_F32, { c.n_embd, 1, 1 }, 1 });
+        if (c.n_expert) {
+            ts.push_back({ b + "ffn_gate_inp.weight", GGML_TYPE_F32, { c.n_embd, c.n_expert, 1 }, 2 });
+            ts.push_back({ b + "ffn_gate_exps.weight", tg, { c.n_embd, c.n_ff, c.n_expert }, 3 });
+            ts.push_back({ b + "ffn_down_exps.weight", td, { c.n_ff, c.n_embd, c.n_expert }, 3 });
+            ts.push_back({ b + "ffn_up_exps.weight", tg, { c.n_embd, c.n_ff, c.n_expert }, 3 });
+        } else {
+            ts.push_back({ b + "ffn_gate.weight", tg, { c.n_embd, c.n_ff, 1 }, 2 });
+            ts.push_back({ b + "ffn_down.weight", td, { c.n_ff, c.n_embd, 1 }, 2 });
+            ts.push_back({ b + "ffn_up.weight", tg, { c.n_embd, c.n_ff, 1 }, 2 });
+        }
+    }
+    return ts;
+}
+
+// Tensor data: seeded N(0, sigma) rows quantized by ggml_quantize_chunk (no imatrix).  To keep writing a 5 GB file to seconds,
+// 61 distinct rows are quantized per tensor and laid out cyclically: every block is a valid block of a real quantizer
+// run; llama-bench feeds random tokens, so the weights need not be meaningful.
+static int write_gguf(const Config & c, const char * path) {
+    gguf_context * g = gguf_init_empty();
+    gguf_set_val_str(g, "general.architecture", "llama");
+    gguf_set_val_str(g, "general.name", c.name);
+    gguf_set_val_u32(g, "general.file_type", !strcmp(c.recipe, "q4_0") ? 2 : 15);
+    gguf_set_val_u32(g, "llama.context_length", 8192);
+    gguf_set_val_u32(g, "llama.embedding_length", c.n_embd);
+    gguf_set_val_u32(g, "llama.block_count", c.n_layer);
+    gguf_set_val_u32(g, "llama.feed_forward_length", c.n_ff);
+    gguf_set_val_u32(g, "llama.attention.head_count", c.n_head);
+    gguf_set_val_u32(g, "llama.attention.head_count_kv", c.n_head_kv);
+    gguf_set_val_f32(g, "llama.attention.layer_norm_rms_epsilon", 1e-5f);
+    gguf_set_val_u32(g, "llama.rope.dimension_count", c.n_embd / c.n_head);
+    gguf_set_val_f32(g, "llama.rope.freq_base", c.rope_base);
+    gguf_set_val_u32(g, "llama.vocab_size", c.n_vocab);
+    if (c.n_expert) {
+        gguf_set_val_u32(g, "llama.expert_count", c.n_expert);
+        gguf_set_val_u32(g, "llama.expert_used_count", c.n_used);
+    }
+    gguf_set_val_str(g, "tokenizer.ggml.model", "no_vocab");
+
+    const std::vector<TensorSpec> ts = tensor_list(c);
+    ggml_init_params ip = { ggml_tensor_overhead() * (ts.size() + 8), nullptr, true };
+    ggml_context * ctx = ggml_init(ip);
+    std::vector<ggml_tensor *> tensors;
+    for (const TensorSpec & t : ts) {
+        ggml_tensor * x = ggml_new_tensor(ctx, t.type, t.n_dims, t.ne);
+        ggml_set_name(x, t.name.c_str());
+        gguf_add_tensor(g, x);
+        tensors.push_back(x);
+    }
+    if (!gguf_write_to_file(g, path, /*only_meta*/ true)) return 1;
+    FILE * f = fopen(path, "ab");
+    if (!f) return 1;
+    const size_t align = gguf_get_alignment(g);
+    std::mt19937 rng(1234);
+    size_t written = 0;
+    constexpr int R = 61;
+    for (size_t i = 0; i < ts.size(); ++i) {
+        const TensorSpec & t = ts[i];
+        const int64_t K = t.ne[0], rows = t.ne[1] * t.ne[2];
+        const size_t row_bytes = ggml_row_size(t.type, K);
+        const bool norm = t.n_dims == 1;
+        const bool router = t.name.find("ffn_gate_inp") != std::string::npos;
+        const int nr = (int) std::min<int64_t>(rows, R);
+        std::vector<float> src((size_t) nr * K);
+        std::normal_distribution<float> nd(norm ? 1.0f : 0.0f, norm ? 0.05f : router ? 0.5f : 0.02f);
+        for (float & v : src) v = nd(rng);
+        std::vector<uint8_t> q((size_t) nr * row_bytes);
+        if (t.type == GGML_TYPE_F32) memcpy(q.data(), src.data(), q.size());
+        else ggml_quantize_chunk(t.type, src.data(), q.data(), 0, nr, K, nullptr);
+        std::vector<uint8_t> chunk;
+        chunk.reserve((size_t) 4096 * row_bytes);
+        for (int64_t r = 0; r < rows; ++r) {
+            const uint8_t * p = q.data() + (size_t) ((r * 7 + r / R) % nr) * row_bytes;
+            chunk.insert(chunk.end(), p, p + row_bytes);
+            if (chunk.size() >= ((size_t) 8 << 20) || r == rows - 1) {
+                if (fwrite(chunk.data(), 1, chunk.size(), f) != chunk.size()) return 1;
+                written += chunk.size();
+                chunk.clear();
+            }
+        }
+        const size_t pad = (align - written % align) % align;
+        static const uint8_t zeros[256] = { 0 };
+        if (pad && fwrite(zeros, 1, pad, f) != pad) return 1;
+        written += pad;
+    }
+    fclose(f);
+    fprintf(stderr, "wrote %s: %zu tensors, %.2f GB\n", path, ts.size(), written / 1e9);
+    ggml_free(ctx);
+    gguf_free(g);
+    return 0;
+}
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static void quiet_log(ggml_log_level level, const char * text, void *) {
+    if (level >= GGML_LOG_LEVEL_WARN) fputs(text, stderr);
+}
+
+struct Session {
+    llama_model *   model = nullptr;
+    llama_context * ctx = nullptr;
+    int             n_vocab = 0;
+    bool open(const char * gguf, int ngl, int n_ctx, int n_batch, int threads) {
+        llama_model_params mp = llama_model_default_params();
+        mp.n_gpu_layers = ngl;
+        model = llama_model_load_from_file(gguf, mp);
+        if (!model) return false;
+        llama_context_params cp = llama_context_default_params();
+        cp.n_ctx = n_ctx;
+        cp.n_batch = n_batch;
+        cp.n_ubatch = n_batch;                     // llama-bench default: -ub 512 = -b 2048 capped to the prompt
+        cp.n_threads = threads;
+        cp.n_threads_batch = threads;
+        cp.no_perf = true;
+        ctx = llama_init_from_model(model, cp);
+        if (!ctx) return false;
+        n_vocab = llama_vocab_n_tokens(llama_model_get_vocab(model));
+        return true;
+    }
+    void close() {
+        if (ctx) llama_free(ctx);
+        if (model) llama_model_free(model);
+        ctx = nullptr;
+        model = nullptr;
+    }
+};
+
+// examples/llama-bench/llama-bench.cpp:1428-1453
+static int test_prompt(Session & s, int n_prompt, int n_batch) {
+    std::vector<llama_token> tokens(n_batch);
+    int done = 0;
+    while (done < n_prompt) {
+        const int n = std::min(n_prompt - done, n_batch);
+        for (int i = 0; i < n; ++i) tokens[i] = std::rand() % s.n_vocab;
+        if (llama_decode(s.ctx, llama_batch_get_one(tokens.data(), n))) return 1;
+        done += n;
+    }
+    llama_synchronize(s.ctx);
+    return 0;
+}
+// :1455-1467
+static int test_gen(Session & s, int n_gen) {
+    llama_token token = std::rand() % s.n_vocab;
+    for (int i = 0; i < n_gen; ++i) {
+        if (llama_decode(s.ctx, llama_batch_get_one(&token, 1))) return 1;
+        llama_synchronize(s.ctx);
+        token = std::rand() % s.n_vocab;
+    }
+    return 0;
+}
+
+static const char * arg(int argc, char ** argv, const char * key, const char * def) {
+    for (int i = 2; i + 1 < argc; ++i)
+        if (!strcmp(argv[i], key)) return argv[i + 1];
+    return def;
+}
+
+int main(int argc, char ** argv) {
+    if (argc < 2) {
+        fprintf(stderr, "usage: %s write|bench|compare ...\n", argv[0]);
+        return 2;
+    }
+    const std::string mode = argv[1];
+    const char * gguf = arg(argc, argv, "--gguf", "/tmp/synth.gguf");
+    if (mode == "write") {
+        const char * name = arg(argc, argv, "--config", "tiny-q4_k_m");
+        for (const Config & c : CONFIGS)
+            if (!strcmp(c.name, name)) return write_gguf(c, gguf);
+        fprintf(stderr, "unknown config %s\n", name);
+        return 2;
+    }
+    const int threads = atoi(arg(argc, argv, "-t", std::to_string(std::max(1u, std::thread::hardware_concurrency() / 2)).c_str()));
+    llama_log_set(quiet_log, nullptr);
+    ggml_backend_load_all();                       // reads GGML_BACKEND_PATH, as llama-bench does (llama-bench.cpp:1513)
+    llama_backend_init();
+    std::string devs;
+    for (size_t i = 0; i < ggml_backend_dev_count(); ++i) devs += std::string(i ? "," : "") + ggml_backend_dev_name(ggml_backend_dev_get(i));
+
+    if (mode == "bench") {
+        const int ngl = atoi(arg(argc, argv, "--ngl", "99")), n_prompt = atoi(arg(argc, argv, "-p", "512")), n_gen = atoi(arg(argc, argv, "-n", "128")),
+                  reps = atoi(arg(argc, argv, "-r", "3"));
+        Session s;
+        if (!s.open(gguf, ngl, n_prompt + n_gen, std::max(n_prompt, 1), threads)) { fprintf(stderr, "load failed\n"); return 1; }
+        std::srand(1234);
+        if (n_prompt > 0 && test_prompt(s, n_prompt, n_prompt)) return 1;          // warm-up (:1619-1631)
+        if (n_gen > 0 && test_gen(s, 1)) return 1;
+        double pp_s = 0, tg_s = 0;
+        std::vector<double> pps, tgs;
+        for (int r = 0; r < reps; ++r) {
+            llama_kv_self_clear(s.ctx);
+            if (n_prompt > 0) {
+                const double t0 = now_s();
+                if (test_prompt(s, n_prompt, n_prompt)) return 1;
+                pps.push_back(n_prompt / (now_s() - t0));
+            }
+            if (n_gen > 0) {
+                const double t0 = now_s();
+                if (test_gen(s, n_gen)) return 1;
+                tgs.push_back(n_gen / (now_s() - t0));
+            }
+        }
+        for (double v : pps) pp_s += v / pps.size();
+        for (double v : tgs) tg_s += v / tgs.size();
+        printf("{\"mode\": \"bench\", \"gguf\": \"%s\", \"ngl\": %d, \"devices\": \"%s\", \"threads\": %d, \"n_prompt\": %d, \"n_gen\": %d, \"reps\": %d, "
+               "\"pp_tok_s\": %.2f, \"tg_tok_s\": %.2f}\n", gguf, ngl, devs.c_str(), threads, n_prompt, n_gen, reps, pp_s, tg_s);
+        s.close();
+        return 0;
+    }
+    if (mode == "compare") {
+        const int n_prompt = atoi(arg(argc, argv, "-p", "64")), n_gen = atoi(arg(argc, argv, "-n", "8"));
+        std::vector<std::vector<float>> logits[2];
+        std::vector<llama_token> prompt(n_prompt), gen(n_gen);
+        std::srand(4321);
+        int n_vocab = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            Session s;
+            if (!s.open(gguf, pass == 0 ? 0 : 99, n_prompt + n_gen, n_prompt, threads)) { fprintf(stderr, "load failed\n"); return 1; }
+            n_vocab = s.n_vocab;
+            if (pass == 0) {
+                for (auto & t : prompt) t = std::rand() % n_vocab;
+                for (auto & t : gen) t = std::rand() % n_vocab;
+            }
+            if (llama_decode(s.ctx, llama_batch_get_one(prompt.data(), n_prompt))) return 1;
+            const float * l = llama_get_logits_ith(s.ctx, -1);
+            logits[pass].emplace_back(l, l + n_vocab);
+            for (int i = 0; i < n_gen; ++i) {
+                if (llama_decode(s.ctx, llama_batch_get_one(&gen[i], 1))) return 1;
+                l = llama_get_logits_ith(s.ctx, -1);
+                logits[pass].emplace_back(l, l + n_vocab);
+            }
+            s.close();
+        }
+        double worst = 0;
+        int argmax_same = 0;
+        for (size_t i = 0; i < logits[0].size(); ++i) {
+            double num = 0, den = 0;
+            const auto & a = logits[0][i], & b = logits[1][i];
+            for (int j = 0; j < n_vocab; ++j) { num += (double) (a[j] - b[j]) * (a[j] - b[j]); den += (double) a[j] * a[j]; }
+            const double nmse = num / den;
+            worst = std::max(worst, std::isfinite(nmse) ? nmse : 1e30);
+            argmax_same += std::max_element(a.begin(), a.end()) - a.begin() == std::max_element(b.begin(), b.end()) - b.begin();
+        }
+        printf("{\"mode\": \"compare\", \"gguf\": \"%s\", \"devices\": \"%s\", \"n_prompt\": %d, \"n_gen\": %d, \"steps\": %zu, \"worst_nmse\": %.3e, "
+               "\"argmax_agree\": %d}\n", gguf, devs.c_str(), n_prompt, n_gen, logits[0].size(), worst, argmax_same);
+        return 0;
+    }
+    fprintf(stderr, "unknown mode %s\n", mode.c_str());
+    return 2;
+}
