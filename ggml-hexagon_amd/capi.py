@@ -20,6 +20,39 @@ EXPORTS = [
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_dequantize",
     "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
 ]
+# include/ggml_mi355x_ops.h: the glue ops of a transformer layer
+OPS_EXPORTS = [
+    "qmm_op_supported", "qmm_op_compute", "qmm_op_add_rms_norm_supported", "qmm_op_add_rms_norm",
+    "qmm_attn_decode_supported", "qmm_attn_decode",
+]
+
+
+class QmmTensor(C.Structure):
+    """qmm_tensor of include/ggml_mi355x_ops.h (the dsptensor of this boundary)"""
+    _fields_ = [("data", C.c_void_p), ("type", C.c_int32), ("flags", C.c_int32), ("ne", C.c_int64 * 4), ("nb", C.c_int64 * 4),
+                ("op_params", C.c_int32 * 16)]
+
+    @classmethod
+    def make(cls, type_, ne, nb=None, data=0, op_params=()):
+        es = {0: 4, 1: 2, 26: 4}.get(type_, 1)
+        ne = list(ne) + [1] * (4 - len(ne))
+        if nb is None:
+            nb, acc = [], es
+            for n in ne:
+                nb.append(acc)
+                acc *= n
+        t = cls()
+        t.data, t.type, t.flags = data, type_, 0
+        t.ne[:] = ne
+        t.nb[:] = list(nb)
+        for i, v in enumerate(op_params):
+            t.op_params[i] = v
+        return t
+
+
+# enum qmm_op
+(OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_SCALE, OP_SILU, OP_GELU, OP_GELU_QUICK, OP_RELU, OP_TANH, OP_SIGMOID, OP_NEG, OP_EXP, OP_RMS_NORM,
+ OP_ROPE, OP_SOFT_MAX, OP_CPY, OP_GET_ROWS, OP_MUL_MAT_F, OP_RMS_NORM_MUL, OP_SILU_MUL) = range(1, 22)
 
 
 class QmmWeight(C.Structure):

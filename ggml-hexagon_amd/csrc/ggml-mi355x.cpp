@@ -58,6 +58,9 @@ struct mi355x_backend_ctx {
     qmm_event *         ev_copy = nullptr;   // cpy_tensor_async: "src is ready" on the source backend's stream
     std::vector<const ggml_tensor *> fuse_cand;      // scratch of graph_compute's fusion pass
     std::vector<int>                 fuse_uses;
+    std::vector<const ggml_tensor *> skipped;
+    std::vector<char>                done;
+    std::vector<const ggml_tensor *> deferred;       // per node: the SILU whose result this MUL consumes in the same launch
 };
 
 // GGML_MI355X_GLUE=0: offload the quantized MUL_MAT / MUL_MAT_ID only (the round-1 surface); GGML_MI355X_FUSE=0: no fused pairs
@@ -382,32 +385,69 @@ fail:
     return GGML_STATUS_FAILED;
 }
 
-enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, const ggml_tensor * const * nodes, int n_nodes, int * consumed) {
+int glue_op(const ggml_tensor * node);
+
+// byte range a tensor occupies (views: the viewed bytes)
+bool ranges_overlap(const ggml_tensor * x, const ggml_tensor * y) {
+    if (!x->data || !y->data) return false;
+    const char * x0 = (const char *) x->data, * y0 = (const char *) y->data;
+    return x0 < y0 + ggml_nbytes(y) && y0 < x0 + ggml_nbytes(x);
+}
+// may `t` run before the nodes in `skipped` although the graph lists it after them?  Its operands are ready (the caller
+// checked), so the question is memory: ggml-alloc reuses freed blocks, so t's result must not land on anything a skipped
+// node still reads or writes.
+bool can_hoist(const ggml_tensor * t, const std::vector<const ggml_tensor *> & skipped) {
+    for (const ggml_tensor * s : skipped) {
+        if (ranges_overlap(t, s)) return false;
+        for (int j = 0; j < GGML_MAX_SRC && s->src[j]; ++j)
+            if (ranges_overlap(t, s->src[j])) return false;
+    }
+    return true;
+}
+bool is_noop(const ggml_tensor * node) {
+    return ggml_is_empty(node) || node->op == GGML_OP_NONE || node->op == GGML_OP_RESHAPE || node->op == GGML_OP_VIEW ||
+           node->op == GGML_OP_PERMUTE || node->op == GGML_OP_TRANSPOSE;
+}
+
+bool dbg() { static const bool on = getenv("GGML_MI355X_DEBUG") != nullptr; return on; }
+constexpr int LOOKAHEAD = 12;      // nodes scanned for MUL_MATs on the same src1 (q .. rope .. k .. rope .. v; gate, silu, up)
+
+// nodes[0] is the MUL_MAT to run; done[] (parallel to nodes) marks later nodes this call has executed as part of its group
+enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const * nodes, int n_nodes, char * done) {
     const ggml_tensor * dst = nodes[0];
     const ggml_tensor * a = dst->src[0], * b = dst->src[1];
     qmm_ctx * q = ctx->dev->qmm;
     void * st = qmm_stream(q);
-    *consumed = 1;
     if (is_split(a)) return compute_mul_mat_split(ctx, dst);
     const int64_t K = a->ne[0], N = b->ne[1];
     const bool flat = a->ne[2] == 1 && a->ne[3] == 1 && b->ne[2] == 1 && b->ne[3] == 1;
     if (flat) {
-        // group the following MUL_MAT nodes that read the same src1 (wq/wk/wv, ffn gate/up): batch <= 8: one launch per
-        // weight type; larger batches: the 16-bit activation operand is prepared once per group
+        // Group the MUL_MAT nodes that read the same src1 (wq/wk/wv, ffn gate/up): batch <= 8: one launch per weight type (or
+        // one mixed-type launch); larger batches: the 16-bit activation operand is prepared once per group.  In llama.cpp's
+        // graph order they are not neighbours (q, rope(q), k, rope(k), v; gate, silu, up), so the scan looks past other
+        // nodes and hoists a later MUL_MAT when that is safe (can_hoist).
         qmm_weight ws[4];
         int n = 0;
-        for (int i = 0; i < n_nodes && n < 4; ++i) {
+        ws[n++] = qmm_weight{ a->data, (int64_t) a->nb[1], a->ne[1], (float *) dst->data, (int64_t) (dst->nb[1] / sizeof(float)), (int) a->type };
+        std::vector<const ggml_tensor *> & skipped = ctx->skipped;
+        skipped.clear();
+        for (int i = 1; i < n_nodes && i <= LOOKAHEAD && n < 4 && !GGML_MI355X_FUSE_OFF(); ++i) {
             const ggml_tensor * d = nodes[i];
-            if (d->op != GGML_OP_MUL_MAT || d->src[1] != b || !supports_mul_mat(d) || !is_ours(d->src[0])) break;
+            if (done[i] || is_noop(d)) continue;
             const ggml_tensor * w = d->src[0];
-            if (w->ne[2] != 1 || w->ne[3] != 1 || w->ne[0] != K) break;
-            ws[n++] = qmm_weight{ w->data, (int64_t) w->nb[1], w->ne[1], (float *) d->data, (int64_t) (d->nb[1] / sizeof(float)), (int) w->type };
+            if (d->op == GGML_OP_MUL_MAT && d->src[1] == b && !glue_op(d) && supports_mul_mat(d) && is_ours(w) && !is_split(w) && w->ne[2] == 1 &&
+                w->ne[3] == 1 && w->ne[0] == K && (can_hoist(d, skipped) || (dbg() && (fprintf(stderr, "no hoist: %s over %zu nodes (first %s)\n", d->name, skipped.size(), skipped[0]->name), false)))) {
+                ws[n++] = qmm_weight{ w->data, (int64_t) w->nb[1], w->ne[1], (float *) d->data, (int64_t) (d->nb[1] / sizeof(float)), (int) w->type };
+                done[i] = 1;
+                continue;
+            }
+            skipped.push_back(d);
         }
+        if (dbg()) fprintf(stderr, "group of %d at %s (N=%lld)\n", n, dst->name, (long long) N);
         if (qmm_mul_mat_group(q, ws, n, K, (const float *) b->data, N, b->nb[1] / sizeof(float), st)) {
             GGML_LOG_ERROR("MI355X MUL_MAT(%s): %s\n", dst->name, qmm_last_error());
             return GGML_STATUS_FAILED;
         }
-        *consumed = n;
         return GGML_STATUS_SUCCESS;
     }
     // batched / broadcast form: one 2-D product per (i12, i13), src0 broadcast as ggml_compute_forward_mul_mat does
@@ -437,13 +477,22 @@ bool moe_twin(const ggml_tensor * d0, const ggml_tensor * d1) {
     return d0->nb[1] == d1->nb[1] && d0->nb[2] == d1->nb[2] && ggml_are_same_shape(d0, d1);
 }
 
-enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, const ggml_tensor * const * nodes, int n_nodes, int * consumed) {
+enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, ggml_tensor * const * nodes, int n_nodes, char * done) {
     const ggml_tensor * dst = nodes[0];
     const ggml_tensor * as = dst->src[0], * b = dst->src[1], * ids = dst->src[2];
     qmm_ctx * q = ctx->dev->qmm;
-    *consumed = 1;
-    if (n_nodes > 1 && moe_twin(dst, nodes[1])) {
-        const ggml_tensor * dst1 = nodes[1];
+    // the twin (ffn_up_exps after ffn_gate_exps) may sit behind the SILU of the first one
+    int twin = 0;
+    std::vector<const ggml_tensor *> & skipped = ctx->skipped;
+    skipped.clear();
+    for (int i = 1; i < n_nodes && i <= LOOKAHEAD && !twin && !GGML_MI355X_FUSE_OFF(); ++i) {
+        if (done[i] || is_noop(nodes[i])) continue;
+        if (moe_twin(dst, nodes[i]) && can_hoist(nodes[i], skipped)) twin = i;
+        else skipped.push_back(nodes[i]);
+        if (nodes[i]->op == GGML_OP_MUL_MAT_ID && !twin) break;
+    }
+    if (twin) {
+        const ggml_tensor * dst1 = nodes[twin];
         if (qmm_mul_mat_id_pair(q, as->type, as->data, dst1->src[0]->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
                                 (const float *) b->data, b->ne[1], b->nb[1], b->nb[2],
                                 (const int32_t *) ids->data, ids->ne[0], ids->ne[1], ids->nb[1],
@@ -451,7 +500,7 @@ enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, const ggml_tensor 
             GGML_LOG_ERROR("MI355X MUL_MAT_ID(%s, %s): %s\n", dst->name, dst1->name, qmm_last_error());
             return GGML_STATUS_FAILED;
         }
-        *consumed = 2;
+        done[twin] = 1;
         return GGML_STATUS_SUCCESS;
     }
     if (qmm_mul_mat_id(q, as->type, as->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
@@ -616,14 +665,17 @@ void backend_synchronize(ggml_backend_t backend) {
 
 enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
-    // fusion candidates: first nodes of (RMS_NORM | SILU) -> MUL pairs whose result nobody else reads.  One pass collects the
+    // fusion candidates: nodes that disappear into a fused launch when their result has exactly one reader (RMS_NORM / SILU
+    // into the MUL behind them; kq, soft_max, kqv and its permute into the attention launch).  One pass collects the
     // candidates, one pass over all operands strikes those that have a second reader.
     std::vector<const ggml_tensor *> & cand = ctx->fuse_cand;
     cand.clear();
     if (!GGML_MI355X_FUSE_OFF()) {
         for (int i = 0; i + 1 < cgraph->n_nodes; ++i) {
             const ggml_tensor * n0 = cgraph->nodes[i];
-            if ((n0->op == GGML_OP_RMS_NORM || n0->op == GGML_OP_UNARY) && cgraph->nodes[i + 1]->op == GGML_OP_MUL) cand.push_back(n0);
+            if (n0->op == GGML_OP_RMS_NORM || (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU) ||
+                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_PERMUTE || (n0->op == GGML_OP_MUL_MAT && n0->src[0]->type == GGML_TYPE_F16))
+                cand.push_back(n0);
         }
         if (!cand.empty()) {
             std::sort(cand.begin(), cand.end());
@@ -635,7 +687,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                     auto it = std::lower_bound(cand.begin(), cand.end(), n->src[j]);
                     if (it != cand.end() && *it == n->src[j]) ++uses[it - cand.begin()];
                 }
-                if (n->view_src) {
+                if (n->view_src && n->view_src != n->src[0]) {                    // an alias that is not already counted as an operand
                     auto it = std::lower_bound(cand.begin(), cand.end(), (const ggml_tensor *) n->view_src);
                     if (it != cand.end() && *it == n->view_src) ++uses[it - cand.begin()];
                 }
@@ -646,42 +698,108 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         auto it = std::lower_bound(cand.begin(), cand.end(), t);
         return it != cand.end() && *it == t && ctx->fuse_uses[it - cand.begin()] == 1;
     };
-    for (int i = 0; i < cgraph->n_nodes;) {
+    const int n_nodes = cgraph->n_nodes;
+    std::vector<char> & done = ctx->done;
+    done.assign(n_nodes, 0);
+    std::vector<const ggml_tensor *> & deferred = ctx->deferred;
+    deferred.assign(n_nodes, nullptr);
+    for (int i = 0; i < n_nodes; ++i) {
         struct ggml_tensor * node = cgraph->nodes[i];
-        if (ggml_is_empty(node) || node->op == GGML_OP_NONE || node->op == GGML_OP_RESHAPE || node->op == GGML_OP_VIEW ||
-            node->op == GGML_OP_PERMUTE || node->op == GGML_OP_TRANSPOSE) {            // ggml-hexagon.cpp:5561-5566
-            ++i;
-            continue;
-        }
+        if (done[i] || is_noop(node)) continue;                                      // ggml-hexagon.cpp:5561-5566
         enum ggml_status st;
-        int consumed = 1;
         const int gop = glue_op(node);
         if (gop) {
             const ggml_tensor * other = nullptr;
             int fop = 0;
-            if (i + 1 < cgraph->n_nodes && (node->op == GGML_OP_RMS_NORM || node->op == GGML_OP_UNARY) && single_use(node))
-                fop = fused_pair(node, cgraph->nodes[i + 1], &other);
+            if (deferred[i]) {
+                // MUL whose operand is a SILU that was held back: silu(gate) * up in one pass
+                const ggml_tensor * silu = deferred[i];
+                st = compute_glue(ctx, node, QMM_OP_SILU_MUL, silu->src[0], node->src[0] == silu ? node->src[1] : node->src[0], nullptr);
+                if (st != GGML_STATUS_SUCCESS) return st;
+                continue;
+            }
+            if (node->op == GGML_OP_UNARY && ggml_get_unary_op(node) == GGML_UNARY_OP_SILU && single_use(node)) {
+                // find the MUL that reads it (build_ffn: gate, silu, up, mul): hold the SILU back when nothing in between
+                // writes over its input
+                int j = i + 1;
+                bool safe = true;
+                for (; j < n_nodes && j <= i + LOOKAHEAD; ++j) {
+                    const ggml_tensor * t = cgraph->nodes[j];
+                    if (t->src[0] == node || t->src[1] == node) break;
+                    if (!done[j] && !is_noop(t) && ranges_overlap(t, node->src[0])) safe = false;
+                }
+                if (safe && j < n_nodes && j <= i + LOOKAHEAD && fused_pair(node, cgraph->nodes[j], &other) == QMM_OP_SILU_MUL) {
+                    deferred[j] = node;
+                    continue;
+                }
+            }
+            if (node->op == GGML_OP_ADD && i + 2 < n_nodes && !GGML_MI355X_FUSE_OFF()) {
+                // residual add -> RMS_NORM -> MUL by the norm weight: one pass with two results
+                ggml_tensor * rn = cgraph->nodes[i + 1], * mul = cgraph->nodes[i + 2];
+                if (rn->op == GGML_OP_RMS_NORM && rn->src[0] == node && single_use(rn) && fused_pair(rn, mul, &other) == QMM_OP_RMS_NORM_MUL) {
+                    const qmm_tensor a = to_qt(node->src[0]), b = to_qt(node->src[1]), w = to_qt(other), sum = to_qt(node), d = to_qt(mul);
+                    if (qmm_op_add_rms_norm_supported(&a, &b, &w, &sum, &d)) {
+                        float eps;
+                        memcpy(&eps, rn->op_params, sizeof(float));
+                        if (qmm_op_add_rms_norm(ctx->dev->qmm, &a, &b, &w, &sum, &d, eps, qmm_stream(ctx->dev->qmm))) {
+                            GGML_LOG_ERROR("MI355X ADD+RMS_NORM(%s): %s\n", node->name, qmm_last_error());
+                            return GGML_STATUS_FAILED;
+                        }
+                        done[i + 1] = done[i + 2] = 1;
+                        continue;
+                    }
+                }
+            }
+            if (gop == QMM_OP_MUL_MAT_F && node->src[0]->type == GGML_TYPE_F16 && node->src[1]->ne[1] <= 8 && single_use(node) && !GGML_MI355X_FUSE_OFF()) {
+                // kq -> soft_max -> kqv -> permute -> cont (build_attn_mha) for a few tokens: one launch
+                int idx[4], k = 0;
+                for (int j = i + 1; j < n_nodes && j <= i + 8 && k < 4; ++j) {
+                    const ggml_tensor * t = cgraph->nodes[j];
+                    if (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_TRANSPOSE) continue;
+                    idx[k++] = j;
+                }
+                if (k == 4) {
+                    ggml_tensor * sm = cgraph->nodes[idx[0]], * kqv = cgraph->nodes[idx[1]], * pm = cgraph->nodes[idx[2]], * ct = cgraph->nodes[idx[3]];
+                    float scale, max_bias;
+                    memcpy(&scale, (const float *) sm->op_params + 0, sizeof(float));
+                    memcpy(&max_bias, (const float *) sm->op_params + 1, sizeof(float));
+                    if (sm->op == GGML_OP_SOFT_MAX && sm->src[0] == node && sm->src[1] && max_bias == 0.0f && single_use(sm) &&
+                        kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm && kqv->src[0]->type == GGML_TYPE_F16 && single_use(kqv) &&
+                        pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv && single_use(pm) && pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] &&
+                        pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm) {
+                        const qmm_tensor q = to_qt(node->src[1]), kk = to_qt(node->src[0]), v = to_qt(kqv->src[0]), m = to_qt(sm->src[1]), d = to_qt(ct);
+                        if (qmm_attn_decode_supported(&q, &kk, &v, &m, &d)) {
+                            if (qmm_attn_decode(ctx->dev->qmm, &q, &kk, &v, &m, &d, scale, qmm_stream(ctx->dev->qmm))) {
+                                GGML_LOG_ERROR("MI355X attention(%s): %s\n", node->name, qmm_last_error());
+                                return GGML_STATUS_FAILED;
+                            }
+                            for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
+                            continue;
+                        }
+                    }
+                }
+            }
+            if (i + 1 < n_nodes && node->op == GGML_OP_RMS_NORM && single_use(node)) fop = fused_pair(node, cgraph->nodes[i + 1], &other);
             if (fop) {
                 ggml_tensor * out = cgraph->nodes[i + 1];
                 ggml_tensor tmp = *out;                                              // dst of the pair, carrying the first node's op_params (eps)
                 memcpy(tmp.op_params, node->op_params, sizeof(tmp.op_params));
                 st = compute_glue(ctx, &tmp, fop, node->src[0], other, nullptr);
-                consumed = 2;
+                done[i + 1] = 1;
             } else if (gop == QMM_OP_CPY) {
                 st = compute_glue(ctx, node, gop, node->src[0], nullptr, nullptr);
             } else {
                 st = compute_glue(ctx, node, gop, node->src[0], node->src[1], node->src[2]);
             }
         } else if (node->op == GGML_OP_MUL_MAT) {
-            st = compute_mul_mat(ctx, cgraph->nodes + i, cgraph->n_nodes - i, &consumed);
+            st = compute_mul_mat(ctx, cgraph->nodes + i, n_nodes - i, done.data() + i);
         } else if (node->op == GGML_OP_MUL_MAT_ID) {
-            st = compute_mul_mat_id(ctx, cgraph->nodes + i, cgraph->n_nodes - i, &consumed);
+            st = compute_mul_mat_id(ctx, cgraph->nodes + i, n_nodes - i, done.data() + i);
         } else {
             GGML_LOG_ERROR("MI355X: op %s (%s) is outside the offloaded surface\n", ggml_op_name(node->op), node->name);
             st = GGML_STATUS_FAILED;
         }
         if (st != GGML_STATUS_SUCCESS) return st;
-        i += consumed;
     }
     // the scheduler reads results right after graph_compute/synchronize; a bad expert id surfaces here
     if (qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm))) {

@@ -61,7 +61,7 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-// block-wide reductions over 256 threads (4 waves) through 4 floats of LDS
+// block-wide reductions (up to 16 waves) through 16 floats of LDS
 template <bool MAX> __device__ __forceinline__ float block_reduce(float v, float * red) {
     v = MAX ? wave_max(v) : wave_sum(v);
     __syncthreads();
@@ -184,6 +184,57 @@ rms_norm_kernel(const char * __restrict__ x, const float * __restrict__ w, char 
         }
     } else {
         for (uint32_t i = threadIdx.x; i < n; i += 256) py[i] = MUL ? px[i] * scale * w[i] : px[i] * scale;
+    }
+}
+
+// The same for rows of up to NT*16 floats with 16-byte aligned rows: the row is read once with float4 loads and kept in
+// registers, the norm weight is requested before the reduction so its latency hides behind it.  Few rows (token generation)
+// run with 1024 threads per row, many rows (prefill) with 256.
+// ADD: x = a + b first, also written to `s` — the residual add that feeds the norm (ffn_inp = cur + inpSA; next layer's
+// inpL = ffn_out + ffn_inp, src/llama-model.cpp:4280, 4340-4346) in the same pass.
+template <bool MUL, bool ADD, int NT>
+__global__ void __launch_bounds__(NT)
+rms_norm_vec_kernel(const char * __restrict__ x, const char * __restrict__ b, const float * __restrict__ w, char * __restrict__ y,
+                    char * __restrict__ s, const Shape sx, const Shape sb, const Shape sy, const Shape ss, const float eps) {
+    __shared__ float red[16];
+    uint32_t i1, i2, i3;
+    row_coords(blockIdx.x, (uint32_t) sx.ne[1], (uint32_t) sx.ne[2], i1, i2, i3);
+    const float4 * px = (const float4 *) (x + i1 * sx.nb[1] + i2 * sx.nb[2] + i3 * sx.nb[3]);
+    float4 *       py = (float4 *) (y + i1 * sy.nb[1] + i2 * sy.nb[2] + i3 * sy.nb[3]);
+    const uint32_t n4 = (uint32_t) sx.ne[0] / 4;
+    float4 v[4], wv[4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = threadIdx.x + j * NT;
+        v[j] = i < n4 ? px[i] : make_float4(0, 0, 0, 0);
+        if (MUL) wv[j] = i < n4 ? ((const float4 *) w)[i] : make_float4(0, 0, 0, 0);
+    }
+    if (ADD) {
+        const float4 * pb = (const float4 *) (b + i1 * sb.nb[1] + i2 * sb.nb[2] + i3 * sb.nb[3]);
+        float4 *       ps = (float4 *) (s + i1 * ss.nb[1] + i2 * ss.nb[2] + i3 * ss.nb[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = threadIdx.x + j * NT;
+            if (i < n4) {
+                const float4 t = pb[i];
+                v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w;
+                ps[i] = v[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    sum = block_reduce<false>(sum, red);
+    const float scale = 1.0f / sqrtf(sum / (float) sx.ne[0] + eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = threadIdx.x + j * NT;
+        if (i < n4) {
+            float4 r = make_float4(v[j].x * scale, v[j].y * scale, v[j].z * scale, v[j].w * scale);
+            if (MUL) { r.x *= wv[j].x; r.y *= wv[j].y; r.z *= wv[j].z; r.w *= wv[j].w; }
+            py[i] = r;
+        }
     }
 }
 
@@ -441,6 +492,109 @@ mul_mat_dot_kernel(const MmArgs g) {
     if (lane == 0) *(float *) (g.d + (int64_t) i12 * g.d_nb2 + (int64_t) i13 * g.d_nb3 + (int64_t) n * g.d_nb1 + (int64_t) m * 4) = s;
 }
 
+// ------------------------------------------------------------------------------------------------ attention, few tokens
+// The chain build_attn_mha emits without flash attention (src/llama-graph.cpp:1166-1203),
+//     kq = mul_mat(k, q);  p = soft_max_ext(kq, mask, scale);  kqv = mul_mat(v, p);  cont(permute(kqv, 0, 2, 1, 3))
+// for a batch of a few tokens (token generation) as ONE launch instead of four: a workgroup owns one (head, token), keeps the
+// n_kv scores in LDS and writes its head's slice of the merged output row.  Arithmetic as the CPU path has it: q and p are
+// rounded to f16 (vec_dot_type of an F16 src0 is F16, ggml-cpu.c type_traits_cpu), products accumulate in f32, the softmax
+// is the one of soft_max_kernel.  K rows are [D] f16 (dense), V is the transposed cache: row d holds n_kv f16.
+struct AttnArgs {
+    const char * q; const char * k; const char * v; const char * mask; char * dst;
+    int64_t q_nb1, q_nb2, k_nb1, k_nb2, v_nb1, v_nb2, m_nb1, d_nb1;
+    int32_t D, Dv, n_kv, H, gqa;
+    float   scale;
+};
+// 16 waves per workgroup and several independent loads in flight per lane: with one (head, token) per workgroup the kernel is
+// bound by load latency, not bandwidth (the first version, 4 waves and one row per lane group at a time, took 22 us at
+// n_kv = 640; the four separate launches it replaces took 16).
+template <int D>
+__global__ void __launch_bounds__(1024)
+attn_decode_kernel(const AttnArgs g) {
+    extern __shared__ float sc[];                       // n_kv scores, then probabilities
+    __shared__ float red[16];
+    const int h = blockIdx.x, n = blockIdx.y, hk = h / g.gqa;
+    const int tid = threadIdx.x, l8 = tid & 7, grp = tid >> 3;          // 128 groups of 8 lanes: one K row per group
+    constexpr int CH = D / 8;                           // halves of a K row per lane
+    constexpr int NV = CH / 8;                          // 16-byte loads per lane and row
+    float qf[CH];
+    {
+        const float * pq = (const float *) (g.q + (int64_t) n * g.q_nb1 + (int64_t) h * g.q_nb2) + l8 * CH;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) qf[e] = (float) (_Float16) pq[e];
+    }
+    const float * pm = (const float *) (g.mask + (int64_t) n * g.m_nb1);
+    const char *  pk = g.k + (int64_t) hk * g.k_nb2 + (int64_t) l8 * CH * 2;
+    float mx = -INFINITY;
+    for (int j0 = grp; j0 < g.n_kv; j0 += 256) {        // two rows (j0, j0 + 128) per trip, their loads issued together
+        h16x8 kv[2][NV];
+        float mk[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = j0 + r * 128;
+            const int jc = j < g.n_kv ? j : j0;
+            const h16x8 * row = (const h16x8 *) (pk + (int64_t) jc * g.k_nb1);
+#pragma unroll
+            for (int c = 0; c < NV; ++c) kv[r][c] = row[c];
+            mk[r] = pm[jc];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = j0 + r * 128;
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float) kv[r][c][e] * qf[c * 8 + e];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s = s * g.scale + mk[r];
+            if (j < g.n_kv) {
+                if (l8 == 0) sc[j] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+    }
+    mx = block_reduce<true>(mx, red);                   // its barriers also publish sc[]
+    float sum = 0.0f;
+    for (int j = tid; j < g.n_kv; j += 1024) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = block_reduce<false>(sum, red);
+    const float inv = 1.0f / sum;
+    for (int j = tid; j < g.n_kv; j += 1024) sc[j] = (float) (_Float16) (sc[j] * inv);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    float * out = (float *) (g.dst + (int64_t) n * g.d_nb1) + (int64_t) h * g.Dv;
+    const char * pv = g.v + (int64_t) hk * g.v_nb2;
+    for (int d0 = wave; d0 < g.Dv; d0 += 64) {          // four V rows (d0, +16, +32, +48) per trip
+        float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        for (int j = lane * 8; j < g.n_kv; j += 512) {
+            h16x8 vv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = d0 + 16 * r < g.Dv ? d0 + 16 * r : d0;
+                vv[r] = *(const h16x8 *) (pv + (int64_t) d * g.v_nb1 + (int64_t) j * 2);
+            }
+            float p[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p[e] = sc[j + e];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[r] += (float) vv[r][e] * p[e];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = wave_sum(acc[r]);
+            if (lane == 0 && d0 + 16 * r < g.Dv) out[d0 + 16 * r] = t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ support predicates
 
 bool is_binary(int op) { return op >= QMM_OP_ADD && op <= QMM_OP_DIV; }
@@ -585,6 +739,41 @@ int launch_mul_mat_f(hipStream_t st, const qmm_tensor * a, const qmm_tensor * b,
     return QMM_OK;
 }
 
+template <bool MUL, bool ADD>
+int launch_rms_norm_vec(hipStream_t st, const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * w, const qmm_tensor * d, const qmm_tensor * sum,
+                        float eps) {
+    const unsigned rows = (unsigned) nrows(d);
+    const bool wide = rows < 256 || a->ne[0] > 256 * 16;
+    const Shape sb = b ? shape_of(b) : shape_of(a), ss = sum ? shape_of(sum) : shape_of(d);
+    if (wide)
+        hipLaunchKernelGGL((rms_norm_vec_kernel<MUL, ADD, 1024>), dim3(rows), dim3(1024), 0, st, (const char *) a->data, b ? (const char *) b->data : nullptr,
+                           w ? (const float *) w->data : nullptr, (char *) d->data, sum ? (char *) sum->data : nullptr, shape_of(a), sb, shape_of(d), ss, eps);
+    else
+        hipLaunchKernelGGL((rms_norm_vec_kernel<MUL, ADD, 256>), dim3(rows), dim3(256), 0, st, (const char *) a->data, b ? (const char *) b->data : nullptr,
+                           w ? (const float *) w->data : nullptr, (char *) d->data, sum ? (char *) sum->data : nullptr, shape_of(a), sb, shape_of(d), ss, eps);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+// y = rms_norm(a [+ b]) [* w]; `sum` receives a + b when b is given
+int launch_rms_norm(hipStream_t st, const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * w, const qmm_tensor * d, const qmm_tensor * sum, float eps) {
+    if (eps < 0.0f) return fail(QMM_EINVAL, "RMS_NORM: eps < 0");
+    const bool vec = a->ne[0] % 4 == 0 && a->ne[0] <= 1024 * 16 && aligned_to(a, 16) && aligned_to(d, 16) && (!w || (uintptr_t) w->data % 16 == 0) &&
+                     (!b || (aligned_to(b, 16) && aligned_to(sum, 16)));
+    if (vec) {
+        if (b) return w ? launch_rms_norm_vec<true, true>(st, a, b, w, d, sum, eps) : launch_rms_norm_vec<false, true>(st, a, b, w, d, sum, eps);
+        return w ? launch_rms_norm_vec<true, false>(st, a, b, w, d, sum, eps) : launch_rms_norm_vec<false, false>(st, a, b, w, d, sum, eps);
+    }
+    if (b) return fail(QMM_EUNSUPPORTED, "ADD + RMS_NORM: rows must be 16-byte aligned, ne0 %% 4 == 0 and ne0 <= 16384");
+    const dim3 grid((unsigned) nrows(d));
+    if (w) hipLaunchKernelGGL((rms_norm_kernel<true>), grid, dim3(256), 0, st, (const char *) a->data, (const float *) w->data, (char *) d->data,
+                              shape_of(a), shape_of(d), eps);
+    else   hipLaunchKernelGGL((rms_norm_kernel<false>), grid, dim3(256), 0, st, (const char *) a->data, (const float *) nullptr, (char *) d->data,
+                              shape_of(a), shape_of(d), eps);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
 float f32_param(const qmm_tensor * d, int i) {
     float v;
     memcpy(&v, &d->op_params[i], sizeof(float));
@@ -619,6 +808,14 @@ int qmm_op_supported(int op, const qmm_tensor * a, const qmm_tensor * b, const q
     }
 }
 
+int qmm_op_add_rms_norm_supported(const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * w, const qmm_tensor * sum, const qmm_tensor * dst) {
+    if (!a || !b || !sum || !dst || !sup_rms_norm(sum, dst) || !sup_binary(a, b, sum) || !same_shape(a, b) || !dense_rows(b)) return 0;
+    if (a->ne[0] % 4 || a->ne[0] > 1024 * 16 || a->nb[1] % 16 || a->nb[2] % 16 || a->nb[3] % 16 || b->nb[1] % 16 || b->nb[2] % 16 || b->nb[3] % 16 ||
+        sum->nb[1] % 16 || sum->nb[2] % 16 || sum->nb[3] % 16 || dst->nb[1] % 16 || dst->nb[2] % 16 || dst->nb[3] % 16) return 0;
+    if (w && !(w->type == G_F32 && contiguous(w) && w->ne[0] == a->ne[0] && nelements(w) == w->ne[0])) return 0;
+    return 1;
+}
+
 int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * c, const qmm_tensor * d, void * stream) {
     if (!ctx || !d) return fail(QMM_EINVAL, "qmm_op_compute: NULL context or dst");
     if (!qmm_op_supported(op, a, b, c, d)) return fail(QMM_EUNSUPPORTED, "qmm_op_compute: op %d with these types / shapes / strides is not implemented", op);
@@ -640,19 +837,8 @@ int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * a, const qmm_tensor
         case QMM_OP_EXP:        return launch_unary<QMM_OP_EXP, false>(st, a, nullptr, d, 0);
         case QMM_OP_SILU_MUL:   return launch_unary<QMM_OP_SILU, true>(st, a, b, d, 0);
         case QMM_OP_RMS_NORM:
-        case QMM_OP_RMS_NORM_MUL: {
-            const float eps = f32_param(d, 0);
-            if (eps < 0.0f) return fail(QMM_EINVAL, "RMS_NORM: eps < 0");
-            const dim3 grid((unsigned) nrows(d));
-            if (op == QMM_OP_RMS_NORM_MUL)
-                hipLaunchKernelGGL((rms_norm_kernel<true>), grid, dim3(256), 0, st, (const char *) a->data, (const float *) b->data, (char *) d->data,
-                                   shape_of(a), shape_of(d), eps);
-            else
-                hipLaunchKernelGGL((rms_norm_kernel<false>), grid, dim3(256), 0, st, (const char *) a->data, (const float *) nullptr, (char *) d->data,
-                                   shape_of(a), shape_of(d), eps);
-            HIP_TRY(hipGetLastError());
-            return QMM_OK;
-        }
+        case QMM_OP_RMS_NORM_MUL:
+            return launch_rms_norm(st, a, nullptr, op == QMM_OP_RMS_NORM_MUL ? b : nullptr, d, nullptr, f32_param(d, 0));
         case QMM_OP_ROPE: {
             RopeParams rp;
             rp.n_dims = d->op_params[1];
@@ -709,6 +895,51 @@ int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * a, const qmm_tensor
         case QMM_OP_MUL_MAT_F: return launch_mul_mat_f(st, a, b, d);
         default: return fail(QMM_EUNSUPPORTED, "qmm_op_compute: unknown op %d", op);
     }
+}
+
+int qmm_op_add_rms_norm(qmm_ctx * ctx, const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * w, const qmm_tensor * sum,
+                        const qmm_tensor * dst, float eps, void * stream) {
+    if (!ctx || !qmm_op_add_rms_norm_supported(a, b, w, sum, dst)) return fail(QMM_EUNSUPPORTED, "qmm_op_add_rms_norm: operands not supported");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return launch_rms_norm(ctx->s(stream), a, b, w, dst, sum, eps);
+}
+
+int qmm_attn_decode_supported(const qmm_tensor * q, const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask, const qmm_tensor * dst) {
+    if (!q || !k || !v || !mask || !dst) return 0;
+    if (q->type != G_F32 || k->type != G_F16 || v->type != G_F16 || mask->type != G_F32 || dst->type != G_F32) return 0;
+    const int64_t D = k->ne[0], n_kv = k->ne[1], Hk = k->ne[2], N = q->ne[1], H = q->ne[2], Dv = v->ne[1];
+    if (D != 64 && D != 128 && D != 256) return 0;
+    if (q->ne[0] != D || v->ne[0] != n_kv || v->ne[2] != Hk || Hk <= 0 || H % Hk || q->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1) return 0;
+    if (N < 1 || N > 8 || n_kv < 8 || n_kv % 8 || n_kv > 16384 || Dv < 1 || Dv > 1024 || H > 65535) return 0;
+    if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || mask->nb[0] != 4 || dst->nb[0] != 4) return 0;
+    if (mask->ne[0] != n_kv || mask->ne[1] < N || dst->ne[0] != Dv * H || dst->ne[1] != N || dst->ne[2] != 1 || dst->ne[3] != 1) return 0;
+    if (q->nb[1] % 4 || q->nb[2] % 4 || k->nb[1] % 16 || k->nb[2] % 16 || v->nb[1] % 16 || v->nb[2] % 16 || mask->nb[1] % 4 || dst->nb[1] % 4) return 0;
+    return 1;
+}
+
+int qmm_attn_decode(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask, const qmm_tensor * dst,
+                    float scale, void * stream) {
+    if (!ctx || !qmm_attn_decode_supported(q, k, v, mask, dst)) return fail(QMM_EUNSUPPORTED, "qmm_attn_decode: operands not supported");
+    if ((uintptr_t) k->data % 16 || (uintptr_t) v->data % 16) return fail(QMM_EINVAL, "qmm_attn_decode: K / V must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    AttnArgs g;
+    g.q = (const char *) q->data; g.k = (const char *) k->data; g.v = (const char *) v->data; g.mask = (const char *) mask->data; g.dst = (char *) dst->data;
+    g.q_nb1 = q->nb[1]; g.q_nb2 = q->nb[2]; g.k_nb1 = k->nb[1]; g.k_nb2 = k->nb[2]; g.v_nb1 = v->nb[1]; g.v_nb2 = v->nb[2];
+    g.m_nb1 = mask->nb[1]; g.d_nb1 = dst->nb[1];
+    g.D = (int32_t) k->ne[0]; g.Dv = (int32_t) v->ne[1]; g.n_kv = (int32_t) k->ne[1]; g.H = (int32_t) q->ne[2]; g.gqa = (int32_t) (q->ne[2] / k->ne[2]);
+    g.scale = scale;
+    const dim3 grid((unsigned) g.H, (unsigned) q->ne[1]);
+    const size_t lds = (size_t) g.n_kv * 4;
+    hipStream_t st = ctx->s(stream);
+    if (g.D == 64) {
+        hipLaunchKernelGGL((attn_decode_kernel<64>), grid, dim3(1024), lds, st, g);
+    } else if (g.D == 128) {
+        hipLaunchKernelGGL((attn_decode_kernel<128>), grid, dim3(1024), lds, st, g);
+    } else {
+        hipLaunchKernelGGL((attn_decode_kernel<256>), grid, dim3(1024), lds, st, g);
+    }
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
 }
 
 } // extern "C"

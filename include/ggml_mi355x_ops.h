@@ -56,6 +56,25 @@ QMM_API int qmm_op_supported(int op, const qmm_tensor * src0, const qmm_tensor *
 QMM_API int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * src0, const qmm_tensor * src1, const qmm_tensor * src2,
                            const qmm_tensor * dst, void * stream);
 
+/* The residual add that feeds a norm, in one pass: sum = a + b (same shapes), dst = rms_norm(sum) [* w] (w = one f32 row or NULL).
+ * Two results, hence its own entry point.  In llama.cpp's layer: ffn_inp = cur + inpSA -> ffn_norm, and the layer's output
+ * add -> the next layer's attn_norm (src/llama-model.cpp:4280-4300, 4340-4346). */
+QMM_API int qmm_op_add_rms_norm_supported(const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * w, const qmm_tensor * sum,
+                                          const qmm_tensor * dst);
+QMM_API int qmm_op_add_rms_norm(qmm_ctx * ctx, const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * w, const qmm_tensor * sum,
+                                const qmm_tensor * dst, float eps, void * stream);
+
+/* Attention for a batch of up to 8 tokens in one launch: the chain build_attn_mha emits without flash attention
+ * (src/llama-graph.cpp:1166-1203): dst = cont(permute(mul_mat(v, soft_max_ext(mul_mat(k, q), mask, scale)), 0, 2, 1, 3)).
+ *   q    f32 [D, N, H]       (any row / head strides)        k  f16 [D, n_kv, H_kv]   rows dense, 16-byte aligned
+ *   v    f16 [n_kv, Dv, H_kv] the transposed V cache          mask f32 [n_kv, >= N]
+ *   dst  f32 [Dv * H, N]
+ * D in {64, 128, 256}, n_kv a multiple of 8 (llama.cpp pads it to 32), H a multiple of H_kv (grouped-query attention). */
+QMM_API int qmm_attn_decode_supported(const qmm_tensor * q, const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask,
+                                      const qmm_tensor * dst);
+QMM_API int qmm_attn_decode(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask,
+                            const qmm_tensor * dst, float scale, void * stream);
+
 #ifdef __cplusplus
 }
 #endif

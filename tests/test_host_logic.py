@@ -17,12 +17,13 @@ def test_capi_exports_every_declared_symbol():
     from ggml_hexagon_amd import build, capi
     so = build.build_qmm()
     lib = ctypes.CDLL(str(so))
-    header = (ROOT / "include" / "ggml_mi355x_qmm.h").read_text()
-    declared = re.findall(r"QMM_API\s+[\w\s\*]+?\b(qmm_\w+)\s*\(", header)
-    assert len(declared) >= 20
-    for name in declared:
-        assert hasattr(lib, name), f"{name} declared in include/ggml_mi355x_qmm.h but not exported"
-    assert set(declared) == set(capi.EXPORTS)
+    for hdr, exports in (("ggml_mi355x_qmm.h", capi.EXPORTS), ("ggml_mi355x_ops.h", capi.OPS_EXPORTS)):
+        header = (ROOT / "include" / hdr).read_text()
+        declared = re.findall(r"QMM_API\s+[\w\s\*]+?\b(qmm_\w+)\s*\(", header)
+        assert len(declared) >= (20 if hdr.endswith("qmm.h") else 6)
+        for name in declared:
+            assert hasattr(lib, name), f"{name} declared in include/{hdr} but not exported"
+        assert set(declared) == set(exports)
     assert lib.qmm_abi_version() == 1
     lib.qmm_row_size.restype = ctypes.c_size_t
     lib.qmm_row_size.argtypes = [ctypes.c_int, ctypes.c_int64]
@@ -217,3 +218,63 @@ def test_prompt_pass_counts_output_rows_only():
     saved = sum(m.flops(512) - m.flops(1) for g in only for m in g.mats)
     assert full - bench == saved and 0.05 < saved / full < 0.12
     assert wl.flops(1, 1) == wl.flops(1) and wl.algo_bytes(1, 1) == wl.algo_bytes(1)          # token generation is unchanged
+
+
+def test_glue_op_surface_predicates():
+    """qmm_op_supported is pure host logic (no device needed): the surface the plugin's supports_op reports.  Shapes follow
+    llama.cpp's layer graph (src/llama-model.cpp:4191-4350, src/llama-graph.cpp:1126-1213)."""
+    from ggml_hexagon_amd import build, capi
+    from ggml_hexagon_amd.capi import QmmTensor as T
+    lib = ctypes.CDLL(str(build.build_qmm()))
+    P = ctypes.POINTER(capi.QmmTensor)
+    lib.qmm_op_supported.argtypes = [ctypes.c_int, P, P, P, P]
+    lib.qmm_attn_decode_supported.argtypes = [P, P, P, P, P]
+    lib.qmm_op_add_rms_norm_supported.argtypes = [P, P, P, P, P]
+
+    def sup(op, a, b, c, d):
+        r = lambda t: ctypes.byref(t) if t is not None else None
+        return lib.qmm_op_supported(op, r(a), r(b), r(c), r(d))
+
+    F32, F16, I32, BF16, Q4K = 0, 1, 26, 30, 12
+    x = T.make(F32, [4096, 512])
+    w = T.make(F32, [4096])
+    assert sup(capi.OP_RMS_NORM, x, None, None, x) == 1
+    assert sup(capi.OP_RMS_NORM_MUL, x, w, None, x) == 1
+    assert sup(capi.OP_RMS_NORM, T.make(F16, [4096, 512]), None, None, T.make(F16, [4096, 512])) == 0
+    assert sup(capi.OP_ADD, x, x, None, x) == 1 and sup(capi.OP_MUL, x, w, None, x) == 1          # broadcast row
+    assert sup(capi.OP_ADD, x, T.make(F32, [4095]), None, x) == 0                                   # not repeatable
+    assert sup(capi.OP_SILU_MUL, x, x, None, x) == 1
+    # rope: normal and neox yes, m-rope / vision no; positions must be i32 of ne2 entries
+    q = T.make(F32, [128, 32, 512])
+    pos = T.make(I32, [512])
+    rope = lambda mode: T.make(F32, [128, 32, 512], op_params=[0, 128, mode, 0, 8192])
+    assert sup(capi.OP_ROPE, q, pos, None, rope(0)) == 1 and sup(capi.OP_ROPE, q, pos, None, rope(2)) == 1
+    assert sup(capi.OP_ROPE, q, pos, None, rope(8)) == 0 and sup(capi.OP_ROPE, q, pos, None, rope(24)) == 0
+    assert sup(capi.OP_ROPE, q, T.make(I32, [511]), None, rope(0)) == 0
+    # soft_max with an f32 or f16 mask of at least ne01 rows
+    kq = T.make(F32, [640, 512, 32])
+    assert sup(capi.OP_SOFT_MAX, kq, T.make(F32, [640, 512]), None, kq) == 1
+    assert sup(capi.OP_SOFT_MAX, kq, T.make(F16, [640, 512]), None, kq) == 1
+    assert sup(capi.OP_SOFT_MAX, kq, T.make(F32, [640, 256]), None, kq) == 0
+    # cpy: f32 <-> f16 any strides, no bf16 / quantized destinations
+    assert sup(capi.OP_CPY, x, None, None, T.make(F16, [4096, 512])) == 1
+    assert sup(capi.OP_CPY, x, None, None, T.make(BF16, [4096, 512])) == 0
+    assert sup(capi.OP_CPY, x, None, None, T.make(Q4K, [4096, 512])) == 0
+    # get_rows from a quantized embedding table
+    emb = T.make(Q4K, [4096, 32000], nb=[144, 2304, 2304 * 32000, 2304 * 32000])
+    assert sup(capi.OP_GET_ROWS, emb, T.make(I32, [512]), None, x) == 1
+    # KQ: K is a strided view of the f16 cache, Q a permuted f32 tensor; grouped-query broadcast 32 / 8
+    k = T.make(F16, [128, 640, 8], nb=[2, 2048, 256, 2048 * 640])
+    qp = T.make(F32, [128, 512, 32], nb=[4, 16384, 512, 16384 * 512])
+    assert sup(capi.OP_MUL_MAT_F, k, qp, None, T.make(F32, [640, 512, 32])) == 1
+    assert sup(capi.OP_MUL_MAT_F, T.make(F16, [128, 640, 8], nb=[2048, 2, 256, 1]), qp, None, T.make(F32, [640, 512, 32])) == 0   # K not dense along D
+    # the fused forms
+    r = ctypes.byref
+    assert lib.qmm_op_add_rms_norm_supported(r(x), r(x), r(w), r(x), r(x)) == 1
+    assert lib.qmm_op_add_rms_norm_supported(r(x), r(w), r(w), r(x), r(x)) == 0                   # broadcast add is not the residual add
+    q1 = T.make(F32, [128, 1, 32], nb=[4, 16384, 512, 16384])
+    v = T.make(F16, [640, 128, 8], nb=[2, 1280, 1280 * 128, 1280 * 1024])
+    m1 = T.make(F32, [640, 64])
+    out = T.make(F32, [4096, 1])
+    assert lib.qmm_attn_decode_supported(r(q1), r(k), r(v), r(m1), r(out)) == 1
+    assert lib.qmm_attn_decode_supported(r(qp), r(k), r(v), r(T.make(F32, [640, 512])), r(T.make(F32, [4096, 512]))) == 0      # prefill batch
