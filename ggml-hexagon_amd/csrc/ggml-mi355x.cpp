@@ -56,8 +56,15 @@ struct mi355x_backend_ctx {
     mi355x_device_ctx * dev;
     std::string         name;
     qmm_event *         ev_copy = nullptr;   // cpy_tensor_async: "src is ready" on the source backend's stream
-    std::vector<const ggml_tensor *> fuse_cand;      // scratch of graph_compute's fusion pass
-    std::vector<int>                 fuse_uses;
+    // per-graph reader analysis (graph_compute): for every candidate tensor, who reads its memory in this graph
+    struct reader_info { const ggml_tensor * t; int uses; int last_reader; bool glue_only; };
+    std::vector<reader_info>         readers;
+    // results of hoisted MUL_MATs that could not be written in place (their block of the compute buffer is still in use at
+    // the earlier point): they live in `hoist_buf` and every reader gets the pointer swapped in to_qt
+    struct redirect { const ggml_tensor * t; char * data; int last_reader; };
+    std::vector<redirect>            redirects;
+    void *                           hoist_buf = nullptr;
+    size_t                           hoist_bytes = 0, hoist_used = 0;
     std::vector<const ggml_tensor *> skipped;
     std::vector<char>                done;
     std::vector<const ggml_tensor *> deferred;       // per node: the SILU whose result this MUL consumes in the same launch
@@ -410,6 +417,29 @@ bool is_noop(const ggml_tensor * node) {
 }
 
 bool dbg() { static const bool on = getenv("GGML_MI355X_DEBUG") != nullptr; return on; }
+// A MUL_MAT that cannot be hoisted in place (ggml-alloc gave it a block that is still live at the earlier point: in
+// llama.cpp's layer Kcur reuses the block of the pre-RoPE Qcur) is computed into the context's scratch instead; every reader
+// then gets the scratch pointer (to_qt).  Possible when all readers are glue ops of this graph and the result is not a graph
+// output.  Returns NULL when it is not.
+void * hoist_elsewhere(mi355x_backend_ctx * ctx, const ggml_tensor * d) {
+    if (d->flags & GGML_TENSOR_FLAG_OUTPUT) return nullptr;
+    auto it = std::lower_bound(ctx->readers.begin(), ctx->readers.end(), d,
+                               [](const mi355x_backend_ctx::reader_info & x, const ggml_tensor * y) { return x.t < y; });
+    if (it == ctx->readers.end() || it->t != d || !it->glue_only || it->uses == 0) return nullptr;
+    const size_t bytes = (ggml_nbytes(d) + 255) & ~(size_t) 255;
+    if (ctx->hoist_used + bytes > ctx->hoist_bytes) {
+        if (ctx->hoist_used || !ctx->redirects.empty()) return nullptr;                // live results in the old block: not this time
+        if (!grow(ctx->dev, ctx->hoist_buf, ctx->hoist_bytes, std::max<size_t>((size_t) 64 << 20, 64 * bytes))) return nullptr;
+    }
+    char * p = (char *) ctx->hoist_buf + ctx->hoist_used;
+    ctx->hoist_used += bytes;
+    // the main loop drops redirects in order of their last reader
+    auto pos = ctx->redirects.begin();
+    while (pos != ctx->redirects.end() && pos->last_reader <= it->last_reader) ++pos;
+    ctx->redirects.insert(pos, { d, p, it->last_reader });
+    return p;
+}
+
 constexpr int LOOKAHEAD = 12;      // nodes scanned for MUL_MATs on the same src1 (q .. rope .. k .. rope .. v; gate, silu, up)
 
 // nodes[0] is the MUL_MAT to run; done[] (parallel to nodes) marks later nodes this call has executed as part of its group
@@ -436,10 +466,14 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
             if (done[i] || is_noop(d)) continue;
             const ggml_tensor * w = d->src[0];
             if (d->op == GGML_OP_MUL_MAT && d->src[1] == b && !glue_op(d) && supports_mul_mat(d) && is_ours(w) && !is_split(w) && w->ne[2] == 1 &&
-                w->ne[3] == 1 && w->ne[0] == K && (can_hoist(d, skipped) || (dbg() && (fprintf(stderr, "no hoist: %s over %zu nodes (first %s)\n", d->name, skipped.size(), skipped[0]->name), false)))) {
-                ws[n++] = qmm_weight{ w->data, (int64_t) w->nb[1], w->ne[1], (float *) d->data, (int64_t) (d->nb[1] / sizeof(float)), (int) w->type };
-                done[i] = 1;
-                continue;
+                w->ne[3] == 1 && w->ne[0] == K) {
+                float * out = (float *) d->data;
+                if (!can_hoist(d, skipped)) out = (float *) hoist_elsewhere(ctx, d);   // its block is still in use here: compute into scratch
+                if (out) {
+                    ws[n++] = qmm_weight{ w->data, (int64_t) w->nb[1], w->ne[1], out, (int64_t) (d->nb[1] / sizeof(float)), (int) w->type };
+                    done[i] = 1;
+                    continue;
+                }
             }
             skipped.push_back(d);
         }
@@ -517,9 +551,14 @@ enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, ggml_tensor * cons
 // ---- glue ops: everything between the quantized MUL_MATs of a layer, so that a layer is one split.
 // The kernel library decides what it implements (qmm_op_supported); this side only translates ggml nodes.
 
-qmm_tensor to_qt(const ggml_tensor * t) {
+qmm_tensor to_qt(const ggml_tensor * t, const mi355x_backend_ctx * ctx = nullptr) {
     qmm_tensor q{};
     q.data = t->data;
+    if (ctx && !ctx->redirects.empty()) {
+        const ggml_tensor * root = t->view_src ? t->view_src : t;
+        for (const auto & r : ctx->redirects)
+            if (r.t == root) q.data = r.data + ((const char *) t->data - (const char *) root->data);
+    }
     q.type = (int32_t) t->type;
     for (int i = 0; i < 4; ++i) { q.ne[i] = t->ne[i]; q.nb[i] = (int64_t) t->nb[i]; }
     memcpy(q.op_params, t->op_params, sizeof(q.op_params));
@@ -576,8 +615,8 @@ enum ggml_status compute_glue(mi355x_backend_ctx * ctx, const ggml_tensor * node
     const qmm_tensor * ps[3] = { nullptr, nullptr, nullptr };
     const ggml_tensor * srcs[3] = { s0, s1, s2 };
     for (int i = 0; i < 3; ++i)
-        if (srcs[i]) { s[i] = to_qt(srcs[i]); ps[i] = &s[i]; }
-    const qmm_tensor d = to_qt(node);
+        if (srcs[i]) { s[i] = to_qt(srcs[i], ctx); ps[i] = &s[i]; }
+    const qmm_tensor d = to_qt(node, ctx);
     if (qmm_op_compute(ctx->dev->qmm, op, ps[0], ps[1], ps[2], &d, qmm_stream(ctx->dev->qmm))) {
         GGML_LOG_ERROR("MI355X %s(%s): %s\n", ggml_op_name(node->op), node->name, qmm_last_error());
         return GGML_STATUS_FAILED;
@@ -606,6 +645,10 @@ const char * backend_get_name(ggml_backend_t backend) { return ((mi355x_backend_
 void backend_free(ggml_backend_t backend) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     if (ctx->ev_copy) qmm_event_destroy(ctx->dev->qmm, ctx->ev_copy);
+    if (ctx->hoist_buf) {
+        qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm));
+        qmm_free(ctx->dev->qmm, ctx->hoist_buf);
+    }
     delete ctx;
     delete backend;
 }
@@ -665,38 +708,47 @@ void backend_synchronize(ggml_backend_t backend) {
 
 enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
-    // fusion candidates: nodes that disappear into a fused launch when their result has exactly one reader (RMS_NORM / SILU
-    // into the MUL behind them; kq, soft_max, kqv and its permute into the attention launch).  One pass collects the
-    // candidates, one pass over all operands strikes those that have a second reader.
-    std::vector<const ggml_tensor *> & cand = ctx->fuse_cand;
-    cand.clear();
+    // Reader analysis.  Candidates are the nodes a fusion wants to skip or move: RMS_NORM / SILU (fused into the MUL behind them),
+    // kq / soft_max / kqv (the attention launch) and the quantized MUL_MATs (grouped with an earlier one on the same src1).
+    // One pass over all operands records, per candidate, how many nodes of this graph read its memory (directly or through
+    // views), the last of them, and whether all of them are glue ops (whose operand pointers this file can redirect).
+    std::vector<mi355x_backend_ctx::reader_info> & rd = ctx->readers;
+    rd.clear();
+    ctx->redirects.clear();
+    ctx->hoist_used = 0;
     if (!GGML_MI355X_FUSE_OFF()) {
         for (int i = 0; i + 1 < cgraph->n_nodes; ++i) {
             const ggml_tensor * n0 = cgraph->nodes[i];
             if (n0->op == GGML_OP_RMS_NORM || (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU) ||
-                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_PERMUTE || (n0->op == GGML_OP_MUL_MAT && n0->src[0]->type == GGML_TYPE_F16))
-                cand.push_back(n0);
+                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT)
+                rd.push_back({ n0, 0, -1, true });
         }
-        if (!cand.empty()) {
-            std::sort(cand.begin(), cand.end());
-            std::vector<int> & uses = ctx->fuse_uses;
-            uses.assign(cand.size(), 0);
+        if (!rd.empty()) {
+            auto less = [](const mi355x_backend_ctx::reader_info & x, const ggml_tensor * t) { return x.t < t; };
+            std::sort(rd.begin(), rd.end(), [](const auto & x, const auto & y) { return x.t < y.t; });
             for (int i = 0; i < cgraph->n_nodes; ++i) {
                 const ggml_tensor * n = cgraph->nodes[i];
+                if (is_noop(n)) continue;                                          // a view reads nothing; its readers are found through view_src
+                const bool glue = glue_op(n) != 0;
                 for (int j = 0; j < GGML_MAX_SRC && n->src[j]; ++j) {
-                    auto it = std::lower_bound(cand.begin(), cand.end(), n->src[j]);
-                    if (it != cand.end() && *it == n->src[j]) ++uses[it - cand.begin()];
-                }
-                if (n->view_src && n->view_src != n->src[0]) {                    // an alias that is not already counted as an operand
-                    auto it = std::lower_bound(cand.begin(), cand.end(), (const ggml_tensor *) n->view_src);
-                    if (it != cand.end() && *it == n->view_src) ++uses[it - cand.begin()];
+                    const ggml_tensor * root = n->src[j]->view_src ? n->src[j]->view_src : n->src[j];
+                    auto it = std::lower_bound(rd.begin(), rd.end(), root, less);
+                    if (it != rd.end() && it->t == root) {
+                        ++it->uses;
+                        it->last_reader = i;
+                        it->glue_only = it->glue_only && glue;
+                    }
                 }
             }
         }
     }
+    auto info = [&](const ggml_tensor * t) -> const mi355x_backend_ctx::reader_info * {
+        auto it = std::lower_bound(rd.begin(), rd.end(), t, [](const mi355x_backend_ctx::reader_info & x, const ggml_tensor * y) { return x.t < y; });
+        return it != rd.end() && it->t == t ? &*it : nullptr;
+    };
     auto single_use = [&](const ggml_tensor * t) {
-        auto it = std::lower_bound(cand.begin(), cand.end(), t);
-        return it != cand.end() && *it == t && ctx->fuse_uses[it - cand.begin()] == 1;
+        const auto * r = info(t);
+        return r && r->uses == 1;
     };
     const int n_nodes = cgraph->n_nodes;
     std::vector<char> & done = ctx->done;
@@ -706,6 +758,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
     for (int i = 0; i < n_nodes; ++i) {
         struct ggml_tensor * node = cgraph->nodes[i];
         if (done[i] || is_noop(node)) continue;                                      // ggml-hexagon.cpp:5561-5566
+        while (!ctx->redirects.empty() && ctx->redirects.front().last_reader < i) ctx->redirects.erase(ctx->redirects.begin());
         enum ggml_status st;
         const int gop = glue_op(node);
         if (gop) {
@@ -737,7 +790,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                 // residual add -> RMS_NORM -> MUL by the norm weight: one pass with two results
                 ggml_tensor * rn = cgraph->nodes[i + 1], * mul = cgraph->nodes[i + 2];
                 if (rn->op == GGML_OP_RMS_NORM && rn->src[0] == node && single_use(rn) && fused_pair(rn, mul, &other) == QMM_OP_RMS_NORM_MUL) {
-                    const qmm_tensor a = to_qt(node->src[0]), b = to_qt(node->src[1]), w = to_qt(other), sum = to_qt(node), d = to_qt(mul);
+                    const qmm_tensor a = to_qt(node->src[0], ctx), b = to_qt(node->src[1], ctx), w = to_qt(other, ctx), sum = to_qt(node, ctx), d = to_qt(mul, ctx);
                     if (qmm_op_add_rms_norm_supported(&a, &b, &w, &sum, &d)) {
                         float eps;
                         memcpy(&eps, rn->op_params, sizeof(float));
@@ -765,9 +818,9 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                     memcpy(&max_bias, (const float *) sm->op_params + 1, sizeof(float));
                     if (sm->op == GGML_OP_SOFT_MAX && sm->src[0] == node && sm->src[1] && max_bias == 0.0f && single_use(sm) &&
                         kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm && kqv->src[0]->type == GGML_TYPE_F16 && single_use(kqv) &&
-                        pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv && single_use(pm) && pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] &&
+                        pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv && pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] &&
                         pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm) {
-                        const qmm_tensor q = to_qt(node->src[1]), kk = to_qt(node->src[0]), v = to_qt(kqv->src[0]), m = to_qt(sm->src[1]), d = to_qt(ct);
+                        const qmm_tensor q = to_qt(node->src[1], ctx), kk = to_qt(node->src[0], ctx), v = to_qt(kqv->src[0], ctx), m = to_qt(sm->src[1], ctx), d = to_qt(ct, ctx);
                         if (qmm_attn_decode_supported(&q, &kk, &v, &m, &d)) {
                             if (qmm_attn_decode(ctx->dev->qmm, &q, &kk, &v, &m, &d, scale, qmm_stream(ctx->dev->qmm))) {
                                 GGML_LOG_ERROR("MI355X attention(%s): %s\n", node->name, qmm_last_error());
@@ -792,7 +845,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                 st = compute_glue(ctx, node, gop, node->src[0], node->src[1], node->src[2]);
             }
         } else if (node->op == GGML_OP_MUL_MAT) {
-            st = compute_mul_mat(ctx, cgraph->nodes + i, n_nodes - i, done.data() + i);
+            st = compute_mul_mat(ctx, cgraph->nodes + i, n_nodes - i, done.data() + i);                      // may hoist later MUL_MATs
         } else if (node->op == GGML_OP_MUL_MAT_ID) {
             st = compute_mul_mat_id(ctx, cgraph->nodes + i, n_nodes - i, done.data() + i);
         } else {
