@@ -23,7 +23,7 @@ EXPORTS = [
 # include/ggml_mi355x_ops.h: the glue ops of a transformer layer
 OPS_EXPORTS = [
     "qmm_op_supported", "qmm_op_compute", "qmm_op_add_rms_norm_supported", "qmm_op_add_rms_norm",
-    "qmm_attn_decode_supported", "qmm_attn_decode",
+    "qmm_attn_decode_supported", "qmm_attn_decode", "qmm_rope_kv_store_supported", "qmm_rope_kv_store",
 ]
 
 

@@ -720,7 +720,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         for (int i = 0; i + 1 < cgraph->n_nodes; ++i) {
             const ggml_tensor * n0 = cgraph->nodes[i];
             if (n0->op == GGML_OP_RMS_NORM || (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU) ||
-                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT)
+                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT || n0->op == GGML_OP_ROPE)
                 rd.push_back({ n0, 0, -1, true });
         }
         if (!rd.empty()) {
@@ -829,6 +829,65 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                             for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
                             continue;
                         }
+                    }
+                }
+            }
+            if (node->op == GGML_OP_ROPE && node->ne[2] <= 8 && !GGML_MI355X_FUSE_OFF()) {
+                // rope(q) with, from further down the graph, rope(k) -> K cache and v -> V cache (build_attn's two ggml_cpy): one launch.
+                // Their inputs must exist already (k and v were hoisted into the q/k/v group); the cache is not compute-buffer
+                // memory, so storing early cannot collide with anything in between.
+                auto ready = [&](const ggml_tensor * t) {                            // was t's root produced before this point?
+                    const ggml_tensor * root = t->view_src ? t->view_src : t;
+                    for (int j = i + 1; j < n_nodes && j <= i + 2 * LOOKAHEAD; ++j)
+                        if (cgraph->nodes[j] == root) return done[j] != 0;
+                    return true;
+                };
+                int jk = -1, jck = -1, jcv = -1;
+                for (int j = i + 1; j < n_nodes && j <= i + 2 * LOOKAHEAD; ++j) {
+                    const ggml_tensor * t = cgraph->nodes[j];
+                    if (done[j] || is_noop(t)) continue;
+                    if (jk < 0 && t->op == GGML_OP_ROPE && t->src[1] == node->src[1] && t->src[2] == node->src[2] && t->ne[0] == node->ne[0] &&
+                        !memcmp(t->op_params, node->op_params, sizeof(t->op_params)) && t->type == GGML_TYPE_F32 && ggml_is_contiguous(t) &&
+                        single_use(t) && ready(t->src[0])) {
+                        jk = j;
+                    } else if (jk >= 0 && jck < 0 && t->op == GGML_OP_CPY && t->src[0] == cgraph->nodes[jk] && t->type == GGML_TYPE_F16 && ggml_is_contiguous(t)) {
+                        jck = j;
+                    } else if (jcv < 0 && t->op == GGML_OP_CPY && t->type == GGML_TYPE_F16 && t->src[0]->type == GGML_TYPE_F32 &&
+                               (t->src[0]->view_src ? t->src[0]->view_src : t->src[0])->op == GGML_OP_MUL_MAT && ready(t->src[0]) &&
+                               (jk < 0 || t->src[0] != cgraph->nodes[jk])) {
+                        jcv = j;
+                    } else if (t->op == GGML_OP_MUL_MAT || t->op == GGML_OP_SOFT_MAX) {
+                        break;                                                         // attention starts: nothing to find beyond
+                    }
+                }
+                if (jk >= 0 && jck < 0) jk = -1;                                       // rope(k) without its store stays where it is
+                if (jk >= 0 || jcv >= 0) {
+                    const qmm_tensor q = to_qt(node->src[0], ctx), pos = to_qt(node->src[1], ctx), qd = to_qt(node, ctx);
+                    qmm_tensor ff{}, k{}, kd{}, v{}, vd{};
+                    if (node->src[2]) ff = to_qt(node->src[2], ctx);
+                    if (jk >= 0) {
+                        const ggml_tensor * rk = cgraph->nodes[jk];
+                        k = to_qt(rk->src[0], ctx);
+                        kd = to_qt(rk, ctx);                                           // shape of rope(k), bytes of the cache view
+                        kd.data = cgraph->nodes[jck]->data;
+                        kd.type = GGML_TYPE_F16;
+                        kd.nb[0] = 2;
+                        for (int a = 1; a < 4; ++a) kd.nb[a] = kd.nb[a - 1] * kd.ne[a - 1];
+                    }
+                    if (jcv >= 0) {
+                        v = to_qt(cgraph->nodes[jcv]->src[0], ctx);
+                        vd = to_qt(cgraph->nodes[jcv], ctx);
+                    }
+                    const qmm_tensor * pff = node->src[2] ? &ff : nullptr, * pk = jk >= 0 ? &k : nullptr, * pkd = jk >= 0 ? &kd : nullptr,
+                                     * pv = jcv >= 0 ? &v : nullptr, * pvd = jcv >= 0 ? &vd : nullptr;
+                    if (qmm_rope_kv_store_supported(&q, &pos, pff, &qd, pk, pkd, pv, pvd)) {
+                        if (qmm_rope_kv_store(ctx->dev->qmm, &q, &pos, pff, &qd, pk, pkd, pv, pvd, qmm_stream(ctx->dev->qmm))) {
+                            GGML_LOG_ERROR("MI355X rope + KV store(%s): %s\n", node->name, qmm_last_error());
+                            return GGML_STATUS_FAILED;
+                        }
+                        if (jk >= 0) done[jk] = done[jck] = 1;
+                        if (jcv >= 0) done[jcv] = 1;
+                        continue;
                     }
                 }
             }

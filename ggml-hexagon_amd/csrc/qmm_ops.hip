@@ -282,21 +282,20 @@ struct RopeParams {
     int   n_dims, neox;
     float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
 };
-__global__ void __launch_bounds__(256)
-rope_kernel(const char * __restrict__ x, const int32_t * __restrict__ pos, const float * __restrict__ ff, char * __restrict__ y,
-            const Shape sx, const Shape sy, const RopeParams rp, const uint32_t total_pairs) {
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    if (gid >= total_pairs) return;
+// one pair of one row; TD = float or __half (the K-cache store of build_attn is rope(k) -> f16)
+template <typename TD>
+__device__ __forceinline__ void rope_pair(const char * __restrict__ x, const int32_t * __restrict__ pos, const float * __restrict__ ff,
+                                          char * __restrict__ y, const Shape & sx, const Shape & sy, const RopeParams & rp, const uint32_t gid) {
     const uint32_t half = (uint32_t) sx.ne[0] / 2;
     const uint32_t p = gid % half;
     uint32_t i1, i2, i3;
     row_coords(gid / half, (uint32_t) sx.ne[1], (uint32_t) sx.ne[2], i1, i2, i3);
     const float * px = (const float *) (x + i1 * sx.nb[1] + i2 * sx.nb[2] + i3 * sx.nb[3]);
-    float *       py = (float *) (y + i1 * sy.nb[1] + i2 * sy.nb[2] + i3 * sy.nb[3]);
+    TD *          py = (TD *) (y + i1 * sy.nb[1] + i2 * sy.nb[2] + i3 * sy.nb[3]);
     const uint32_t i0 = 2 * p;
     if (i0 >= (uint32_t) rp.n_dims) {             // pass-through channels
-        py[i0] = px[i0];
-        py[i0 + 1] = px[i0 + 1];
+        py[i0] = (TD) px[i0];
+        py[i0 + 1] = (TD) px[i0 + 1];
         return;
     }
     float theta = (float) pos[i2];
@@ -313,8 +312,14 @@ rope_kernel(const char * __restrict__ x, const int32_t * __restrict__ pos, const
     const float c = cosf(th) * mscale, s = sinf(th) * mscale;
     const uint32_t ia = rp.neox ? p : i0, ib = rp.neox ? p + rp.n_dims / 2 : i0 + 1;
     const float x0 = px[ia], x1 = px[ib];
-    py[ia] = x0 * c - x1 * s;
-    py[ib] = x0 * s + x1 * c;
+    py[ia] = (TD) (x0 * c - x1 * s);
+    py[ib] = (TD) (x0 * s + x1 * c);
+}
+__global__ void __launch_bounds__(256)
+rope_kernel(const char * __restrict__ x, const int32_t * __restrict__ pos, const float * __restrict__ ff, char * __restrict__ y,
+            const Shape sx, const Shape sy, const RopeParams rp, const uint32_t total_pairs) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid < total_pairs) rope_pair<float>(x, pos, ff, y, sx, sy, rp, gid);
 }
 
 // ------------------------------------------------------------------------------------------------ CPY / CONT / DUP
@@ -363,6 +368,27 @@ cpy_transpose_kernel(const char * __restrict__ x, char * __restrict__ y, const u
         const uint32_t i0 = b0 + tx, i1 = b1 + ty + j * 8;                 // ... and dst's dense direction
         if (i0 < ne0 && i1 < ne1) st_from_f32<TD>(y + (size_t) i0 * sizeof(TD) + (size_t) i1 * sy1, tile[tx][ty + j * 8]);
     }
+}
+
+// What follows the q/k/v projections of a few-token batch in build_attn (src/llama-graph.cpp:1306-1365), as ONE launch:
+//   rope(q) -> f32            rope(k) -> the f16 K cache (ggml_rope_ext + ggml_cpy(k_cur, k_cache_view))
+//   v       -> the f16 (transposed) V cache (ggml_cpy(v_cur^T, v_cache_view))
+// The grid is the concatenation of the three index spaces; k and v parts are optional (nk = 0 / nv = 0).
+struct RopeStoreArgs {
+    const char * q; char * qd; const char * k; char * kd; const char * v; char * vd;
+    const int32_t * pos; const float * ff;
+    Shape sq, sqd, sk, skd, sv, svd;
+    RopeParams rp;
+    uint32_t nq, nk, nv;          // pairs of q, pairs of k, elements of v
+};
+__global__ void __launch_bounds__(256)
+rope_store_kernel(const RopeStoreArgs g) {
+    uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid < g.nq) { rope_pair<float>(g.q, g.pos, g.ff, g.qd, g.sq, g.sqd, g.rp, gid); return; }
+    gid -= g.nq;
+    if (gid < g.nk) { rope_pair<__half>(g.k, g.pos, g.ff, g.kd, g.sk, g.skd, g.rp, gid); return; }
+    gid -= g.nk;
+    if (gid < g.nv) st_from_f32<__half>(g.vd + elem_offset(gid, g.svd), ld_as_f32<float>(g.v + elem_offset(gid, g.sv)));
 }
 
 // ------------------------------------------------------------------------------------------------ GET_ROWS
@@ -788,6 +814,24 @@ void rope_corr_dims(int n_dims, int n_ctx_orig, float freq_base, float beta_fast
     dims[1] = end < n_dims - 1 ? end : n_dims - 1;
 }
 
+// op_params of ggml_rope_ext (ggml.c ggml_rope_impl) -> kernel parameters
+RopeParams rope_params(const qmm_tensor * d) {
+    RopeParams rp;
+    rp.n_dims = d->op_params[1];
+    rp.neox = (d->op_params[2] & 2) != 0;
+    const int n_ctx_orig = d->op_params[4];
+    const float freq_base = f32_param(d, 5), beta_fast = f32_param(d, 9), beta_slow = f32_param(d, 10);
+    rp.freq_scale = f32_param(d, 6);
+    rp.ext_factor = f32_param(d, 7);
+    rp.attn_factor = f32_param(d, 8);
+    rp.theta_scale = powf(freq_base, -2.0f / rp.n_dims);
+    float cd[2];
+    rope_corr_dims(rp.n_dims, n_ctx_orig, freq_base, beta_fast, beta_slow, cd);
+    rp.corr0 = cd[0];
+    rp.corr1 = cd[1];
+    return rp;
+}
+
 } // namespace
 
 extern "C" {
@@ -840,19 +884,7 @@ int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * a, const qmm_tensor
         case QMM_OP_RMS_NORM_MUL:
             return launch_rms_norm(st, a, nullptr, op == QMM_OP_RMS_NORM_MUL ? b : nullptr, d, nullptr, f32_param(d, 0));
         case QMM_OP_ROPE: {
-            RopeParams rp;
-            rp.n_dims = d->op_params[1];
-            rp.neox = (d->op_params[2] & 2) != 0;
-            const int n_ctx_orig = d->op_params[4];
-            const float freq_base = f32_param(d, 5), beta_fast = f32_param(d, 9), beta_slow = f32_param(d, 10);
-            rp.freq_scale = f32_param(d, 6);
-            rp.ext_factor = f32_param(d, 7);
-            rp.attn_factor = f32_param(d, 8);
-            rp.theta_scale = powf(freq_base, -2.0f / rp.n_dims);
-            float cd[2];
-            rope_corr_dims(rp.n_dims, n_ctx_orig, freq_base, beta_fast, beta_slow, cd);
-            rp.corr0 = cd[0];
-            rp.corr1 = cd[1];
+            const RopeParams rp = rope_params(d);
             const uint32_t pairs = (uint32_t) (nelements(d) / 2);
             hipLaunchKernelGGL(rope_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, (const char *) a->data, (const int32_t *) b->data,
                                c ? (const float *) c->data : nullptr, (char *) d->data, shape_of(a), shape_of(d), rp, pairs);
@@ -938,6 +970,38 @@ int qmm_attn_decode(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, c
     } else {
         hipLaunchKernelGGL((attn_decode_kernel<256>), grid, dim3(1024), lds, st, g);
     }
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+int qmm_rope_kv_store_supported(const qmm_tensor * q, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * q_dst,
+                                const qmm_tensor * k, const qmm_tensor * k_dst, const qmm_tensor * v, const qmm_tensor * v_dst) {
+    if (!sup_rope(q, pos, ff, q_dst)) return 0;
+    if (k) {
+        if (!k_dst || k->type != G_F32 || k_dst->type != G_F16 || !same_shape(k, k_dst) || !dense_rows(k) || !dense_rows(k_dst) || !fits_u32(k)) return 0;
+        if (k->ne[0] != q->ne[0] || k->ne[2] != q->ne[2] || k->ne[3] != q->ne[3] || nelements(k) == 0) return 0;
+        if (k->nb[1] % 4 || k->nb[2] % 4 || k->nb[3] % 4 || k_dst->nb[1] % 2 || k_dst->nb[2] % 2 || k_dst->nb[3] % 2) return 0;
+    }
+    if (v) {
+        if (!v_dst || v->type != G_F32 || v_dst->type != G_F16 || nelements(v) != nelements(v_dst) || !fits_u32(v) || nelements(v) == 0) return 0;
+        if (v->nb[0] % 4 || v->nb[1] % 4 || v->nb[2] % 4 || v->nb[3] % 4 || v_dst->nb[0] % 2 || v_dst->nb[1] % 2 || v_dst->nb[2] % 2 || v_dst->nb[3] % 2) return 0;
+    }
+    return nelements(q) / 2 + (k ? nelements(k) / 2 : 0) + (v ? nelements(v) : 0) < ((int64_t) 1 << 31);
+}
+
+int qmm_rope_kv_store(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * q_dst,
+                      const qmm_tensor * k, const qmm_tensor * k_dst, const qmm_tensor * v, const qmm_tensor * v_dst, void * stream) {
+    if (!ctx || !qmm_rope_kv_store_supported(q, pos, ff, q_dst, k, k_dst, v, v_dst)) return fail(QMM_EUNSUPPORTED, "qmm_rope_kv_store: operands not supported");
+    HIP_TRY(hipSetDevice(ctx->device));
+    RopeStoreArgs g;
+    g.q = (const char *) q->data; g.qd = (char *) q_dst->data; g.sq = shape_of(q); g.sqd = shape_of(q_dst);
+    g.k = k ? (const char *) k->data : nullptr; g.kd = k ? (char *) k_dst->data : nullptr; g.sk = shape_of(k ? k : q); g.skd = shape_of(k ? k_dst : q_dst);
+    g.v = v ? (const char *) v->data : nullptr; g.vd = v ? (char *) v_dst->data : nullptr; g.sv = shape_of(v ? v : q); g.svd = shape_of(v ? v_dst : q_dst);
+    g.pos = (const int32_t *) pos->data; g.ff = ff ? (const float *) ff->data : nullptr;
+    g.rp = rope_params(q_dst);
+    g.nq = (uint32_t) (nelements(q) / 2); g.nk = k ? (uint32_t) (nelements(k) / 2) : 0; g.nv = v ? (uint32_t) nelements(v) : 0;
+    const uint32_t total = g.nq + g.nk + g.nv;
+    hipLaunchKernelGGL(rope_store_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->s(stream), g);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }

@@ -75,6 +75,15 @@ QMM_API int qmm_attn_decode_supported(const qmm_tensor * q, const qmm_tensor * k
 QMM_API int qmm_attn_decode(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask,
                             const qmm_tensor * dst, float scale, void * stream);
 
+/* What follows the q / k / v projections of a few-token batch in build_attn (src/llama-graph.cpp:1306-1365), in one launch:
+ *   q_dst = rope(q) (f32; q_dst carries the ROPE node's op_params), k_dst = (f16) rope(k) straight into the K cache view,
+ *   v_dst = (f16) v into the (transposed) V cache view, element i of v (in v's index order) to element i of v_dst, as CPY does.
+ * k / k_dst and v / v_dst are optional pairs (NULL). */
+QMM_API int qmm_rope_kv_store_supported(const qmm_tensor * q, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * q_dst,
+                                        const qmm_tensor * k, const qmm_tensor * k_dst, const qmm_tensor * v, const qmm_tensor * v_dst);
+QMM_API int qmm_rope_kv_store(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * q_dst,
+                              const qmm_tensor * k, const qmm_tensor * k_dst, const qmm_tensor * v, const qmm_tensor * v_dst, void * stream);
+
 #ifdef __cplusplus
 }
 #endif
