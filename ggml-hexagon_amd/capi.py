@@ -14,7 +14,7 @@ MATVEC_MAX_N = 8
 
 EXPORTS = [
     "qmm_abi_version", "qmm_last_error", "qmm_device_count", "qmm_create", "qmm_destroy", "qmm_device", "qmm_stream",
-    "qmm_device_info", "qmm_set_act_mode", "qmm_set_precision", "qmm_malloc", "qmm_free", "qmm_memcpy_h2d",
+    "qmm_device_info", "qmm_set_act_mode", "qmm_set_precision", "qmm_malloc", "qmm_free", "qmm_host_malloc", "qmm_host_free", "qmm_memcpy_h2d",
     "qmm_memcpy_d2h", "qmm_memcpy_d2d", "qmm_memset", "qmm_synchronize", "qmm_memcpy2d_d2d", "qmm_event_create",
     "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_memcpy_h2d_async",
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_dequantize",

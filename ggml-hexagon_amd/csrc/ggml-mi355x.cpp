@@ -174,6 +174,29 @@ const ggml_backend_buffer_type_i buft_iface = {
     /* .is_host        = */ buft_is_host,
 };
 
+// ----------------------------------------------------------------------------------------------- host (pinned) buffer type
+// with caps {async, host_buffer, events} llama.cpp's loader uploads through four pinned staging buffers and
+// events (src/llama-model-loader.cpp:904-1079) and the scheduler gives the CPU backend's compute buffer this type, so the
+// per-token inputs leave from page-locked memory.  The buffer itself is an ordinary CPU buffer over hipHostMalloc'ed memory.
+
+const char * host_buft_get_name(ggml_backend_buffer_type_t) { return GGML_MI355X_BACKEND_NAME "_Host"; }
+void host_buffer_free(ggml_backend_buffer_t buffer) { qmm_host_free(g_devs[0].qmm, buffer->context); }
+ggml_backend_buffer_t host_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    void * p = getenv("GGML_MI355X_NO_PINNED") ? nullptr : qmm_host_malloc(g_devs[0].qmm, size);
+    if (!p) return ggml_backend_buft_alloc_buffer(ggml_backend_cpu_buffer_type(), size);      // pageable memory still works, just slower
+    ggml_backend_buffer_t buffer = ggml_backend_cpu_buffer_from_ptr(p, size);
+    buffer->buft = buft;
+    buffer->iface.free_buffer = host_buffer_free;
+    return buffer;
+}
+ggml_backend_buffer_type_t host_buffer_type() {
+    static ggml_backend_buffer_type buft = {
+        { host_buft_get_name, host_buft_alloc_buffer, ggml_backend_cpu_buffer_type()->iface.get_alignment, nullptr,
+          ggml_backend_cpu_buffer_type()->iface.get_alloc_size, ggml_backend_cpu_buffer_type()->iface.is_host },
+        &g_devices[0], nullptr };
+    return &buft;
+}
+
 // ----------------------------------------------------------------------------------------------- split buffer type
 // ggml row split inside one process (ggml-cuda.cu:727-1052): a weight tensor's rows are divided over the devices by the
 // cumulative fractions of `tensor_split`, boundaries rounded down to 64 rows, the last device takes the remainder
@@ -955,13 +978,15 @@ void dev_get_props(ggml_backend_dev_t dev, struct ggml_backend_dev_props * props
     props->description = dev_get_description(dev);
     props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
     dev_get_memory(dev, &props->memory_free, &props->memory_total);
-    props->caps = { /* async */ true, /* host_buffer */ false, /* buffer_from_host_ptr */ false, /* events */ true };
+    props->caps = { /* async */ true, /* host_buffer */ true, /* buffer_from_host_ptr */ false, /* events */ true };
 }
 ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
     auto * d = (mi355x_device_ctx *) dev->context;
     return new ggml_backend{ backend_guid(), backend_iface, dev, new mi355x_backend_ctx{ d, d->name } };
 }
 ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &((mi355x_device_ctx *) dev->context)->buft; }
+
+ggml_backend_buffer_type_t dev_get_host_buffer_type(ggml_backend_dev_t) { return host_buffer_type(); }
 
 ggml_backend_event_t dev_event_new(ggml_backend_dev_t dev) {
     qmm_event * e = qmm_event_create(((mi355x_device_ctx *) dev->context)->qmm);
@@ -1002,7 +1027,7 @@ const ggml_backend_device_i device_iface = {
     /* .get_props            = */ dev_get_props,
     /* .init_backend         = */ dev_init_backend,
     /* .get_buffer_type      = */ dev_get_buffer_type,
-    /* .get_host_buffer_type = */ nullptr,
+    /* .get_host_buffer_type = */ dev_get_host_buffer_type,
     /* .buffer_from_host_ptr = */ nullptr,
     /* .supports_op          = */ dev_supports_op,
     /* .supports_buft        = */ dev_supports_buft,

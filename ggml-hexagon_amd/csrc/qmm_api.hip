@@ -229,6 +229,23 @@ void qmm_free(qmm_ctx * c, void * p) {
     (void) hipSetDevice(c->device);
     (void) hipFree(p);
 }
+// page-locked host memory: transfers from / to it are real DMA and the *_async copies do not stage (the reference's
+// counterpart is the rpcmem / ION pool shared with the cDSP, ggml-hexagon.cpp:4698-4747)
+void * qmm_host_malloc(qmm_ctx * c, size_t bytes) {
+    if (!c) return nullptr;
+    void * p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void) hipGetLastError();
+        fail(QMM_ENOMEM, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+void qmm_host_free(qmm_ctx * c, void * p) {
+    if (!c || !p) return;
+    (void) hipSetDevice(c->device);
+    (void) hipHostFree(p);
+}
 int qmm_memcpy_h2d(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->s(st)));

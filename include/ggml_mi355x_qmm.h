@@ -86,6 +86,10 @@ QMM_API int          qmm_set_precision(qmm_ctx * ctx, int prec);
 
 QMM_API void *       qmm_malloc(qmm_ctx * ctx, size_t bytes);
 QMM_API void         qmm_free(qmm_ctx * ctx, void * dptr);
+/* page-locked host memory for staging (the rpcmem / ION pool of the reference, ggml-hexagon.cpp:4698-4747): copies from / to it
+ * are DMA transfers and the *_async forms below really are asynchronous */
+QMM_API void *       qmm_host_malloc(qmm_ctx * ctx, size_t bytes);
+QMM_API void         qmm_host_free(qmm_ctx * ctx, void * hptr);
 QMM_API int          qmm_memcpy_h2d(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
 QMM_API int          qmm_memcpy_d2h(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
 QMM_API int          qmm_memcpy_d2d(qmm_ctx * ctx, void * dst, const void * src, size_t bytes, void * stream);
