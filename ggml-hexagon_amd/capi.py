@@ -18,7 +18,7 @@ EXPORTS = [
     "qmm_memcpy_d2h", "qmm_memcpy_d2d", "qmm_memset", "qmm_synchronize", "qmm_memcpy2d_d2d", "qmm_event_create",
     "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_memcpy_h2d_async",
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_dequantize",
-    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
+    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
 ]
 # include/ggml_mi355x_ops.h: the glue ops of a transformer layer
 OPS_EXPORTS = [

@@ -68,6 +68,9 @@ struct mi355x_backend_ctx {
     std::vector<const ggml_tensor *> skipped;
     std::vector<char>                done;
     std::vector<const ggml_tensor *> deferred;       // per node: the SILU whose result this MUL consumes in the same launch
+    // RMS_NORM -> MUL(w) held back for the MUL_MATs that read it (few-token batches): they form the normed row while staging
+    struct norm_req { const ggml_tensor * rn = nullptr, * mul = nullptr, * w = nullptr; int readers = 0; };
+    norm_req                         pending_norm;
 };
 
 // GGML_MI355X_GLUE=0: offload the quantized MUL_MAT / MUL_MAT_ID only (the round-1 surface); GGML_MI355X_FUSE=0: no fused pairs
@@ -416,6 +419,9 @@ fail:
 }
 
 int glue_op(const ggml_tensor * node);
+qmm_tensor to_qt(const ggml_tensor * t, const mi355x_backend_ctx * ctx);
+enum ggml_status compute_glue(mi355x_backend_ctx * ctx, const ggml_tensor * node, int op, const ggml_tensor * s0, const ggml_tensor * s1,
+                              const ggml_tensor * s2);
 
 // byte range a tensor occupies (views: the viewed bytes)
 bool ranges_overlap(const ggml_tensor * x, const ggml_tensor * y) {
@@ -501,7 +507,51 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
             skipped.push_back(d);
         }
         if (dbg()) fprintf(stderr, "group of %d at %s (N=%lld)\n", n, dst->name, (long long) N);
-        if (qmm_mul_mat_group(q, ws, n, K, (const float *) b->data, N, b->nb[1] / sizeof(float), st)) {
+        const float * x = (const float *) b->data;
+        int64_t ldx = b->nb[1] / sizeof(float);
+        qmm_mv_extra ex{};
+        bool use_ex = false;
+        // (a) src1 is a held-back RMS_NORM * w (graph_compute): when the group holds every reader of it the kernels form the normed
+        //     row themselves; otherwise it is materialized now, as the graph says
+        if (ctx->pending_norm.mul == b) {
+            const auto pn = ctx->pending_norm;
+            ctx->pending_norm = {};
+            if (n == pn.readers) {
+                const qmm_tensor qx = to_qt(pn.rn->src[0], ctx);
+                x = (const float *) qx.data;
+                ldx = pn.rn->src[0]->nb[1] / sizeof(float);
+                ex.norm_w = (const float *) pn.w->data;
+                memcpy(&ex.norm_eps, pn.rn->op_params, sizeof(float));
+                use_ex = true;
+            } else {
+                ggml_tensor tmp = *pn.mul;
+                memcpy(tmp.op_params, pn.rn->op_params, sizeof(tmp.op_params));
+                const enum ggml_status s = compute_glue(ctx, &tmp, QMM_OP_RMS_NORM_MUL, pn.rn->src[0], pn.w, nullptr);
+                if (s != GGML_STATUS_SUCCESS) return s;
+            }
+        }
+        // (b) a lone MUL_MAT whose only reader is the residual ADD right behind it (wo, ffn_down): dst = W x + residual, written
+        //     where the ADD would have put it
+        if (n == 1 && N <= QMM_MATVEC_MAX_N && !GGML_MI355X_FUSE_OFF() && !(dst->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+            int j = 1;
+            while (j < n_nodes && (done[j] || is_noop(nodes[j]))) ++j;
+            const ggml_tensor * add = j < n_nodes ? nodes[j] : nullptr;
+            auto it = std::lower_bound(ctx->readers.begin(), ctx->readers.end(), dst,
+                                       [](const mi355x_backend_ctx::reader_info & r, const ggml_tensor * t) { return r.t < t; });
+            const bool single = it != ctx->readers.end() && it->t == dst && it->uses == 1;
+            if (add && single && add->op == GGML_OP_ADD && (add->src[0] == dst || add->src[1] == dst) && add->src[0] != add->src[1]) {
+                const ggml_tensor * r = add->src[0] == dst ? add->src[1] : add->src[0];
+                if (ggml_are_same_shape(r, dst) && ggml_are_same_shape(add, dst) && r->type == GGML_TYPE_F32 && r->nb[0] == 4 && add->nb[0] == 4 &&
+                    r->nb[1] == add->nb[1] && add->nb[1] % 4 == 0) {
+                    ex.residual[0] = (const float *) to_qt(r, ctx).data;
+                    ws[0].dst = (float *) add->data;
+                    ws[0].ldd = (int64_t) (add->nb[1] / sizeof(float));
+                    done[j] = 1;
+                    use_ex = true;
+                }
+            }
+        }
+        if (use_ex ? qmm_mul_mat_group_ex(q, ws, n, K, x, N, ldx, &ex, st) : qmm_mul_mat_group(q, ws, n, K, x, N, ldx, st)) {
             GGML_LOG_ERROR("MI355X MUL_MAT(%s): %s\n", dst->name, qmm_last_error());
             return GGML_STATUS_FAILED;
         }
@@ -574,7 +624,7 @@ enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, ggml_tensor * cons
 // ---- glue ops: everything between the quantized MUL_MATs of a layer, so that a layer is one split.
 // The kernel library decides what it implements (qmm_op_supported); this side only translates ggml nodes.
 
-qmm_tensor to_qt(const ggml_tensor * t, const mi355x_backend_ctx * ctx = nullptr) {
+qmm_tensor to_qt(const ggml_tensor * t, const mi355x_backend_ctx * ctx) {
     qmm_tensor q{};
     q.data = t->data;
     if (ctx && !ctx->redirects.empty()) {
@@ -626,8 +676,8 @@ bool supports_glue(const ggml_tensor * node) {
     qmm_tensor s[3];
     const qmm_tensor * ps[3] = { nullptr, nullptr, nullptr };
     for (int i = 0; i < 3; ++i)
-        if (node->src[i]) { s[i] = to_qt(node->src[i]); ps[i] = &s[i]; }
-    const qmm_tensor d = to_qt(node);
+        if (node->src[i]) { s[i] = to_qt(node->src[i], nullptr); ps[i] = &s[i]; }
+    const qmm_tensor d = to_qt(node, nullptr);
     if (op == QMM_OP_CPY) return qmm_op_supported(op, ps[0], nullptr, nullptr, &d) != 0;
     return qmm_op_supported(op, ps[0], ps[1], ps[2], &d) != 0;
 }
@@ -653,7 +703,7 @@ int fused_pair(const ggml_tensor * n0, const ggml_tensor * n1, const ggml_tensor
     if (n1->op != GGML_OP_MUL || (n1->src[0] != n0 && n1->src[1] != n0) || n1->src[0] == n1->src[1]) return 0;
     *other = n1->src[0] == n0 ? n1->src[1] : n1->src[0];
     if (!ggml_are_same_shape(n0, n1) || (n0->flags & GGML_TENSOR_FLAG_OUTPUT)) return 0;
-    qmm_tensor a = to_qt(n0->src[0]), b = to_qt(*other), d = to_qt(n1);
+    qmm_tensor a = to_qt(n0->src[0], nullptr), b = to_qt(*other, nullptr), d = to_qt(n1, nullptr);
     memcpy(d.op_params, n0->op_params, sizeof(d.op_params));
     if (n0->op == GGML_OP_RMS_NORM && qmm_op_supported(QMM_OP_RMS_NORM_MUL, &a, &b, nullptr, &d)) return QMM_OP_RMS_NORM_MUL;
     if (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU && qmm_op_supported(QMM_OP_SILU_MUL, &a, &b, nullptr, &d))
@@ -743,7 +793,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         for (int i = 0; i + 1 < cgraph->n_nodes; ++i) {
             const ggml_tensor * n0 = cgraph->nodes[i];
             if (n0->op == GGML_OP_RMS_NORM || (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU) ||
-                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT || n0->op == GGML_OP_ROPE)
+                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT || n0->op == GGML_OP_ROPE || n0->op == GGML_OP_MUL)
                 rd.push_back({ n0, 0, -1, true });
         }
         if (!rd.empty()) {
@@ -915,6 +965,33 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                 }
             }
             if (i + 1 < n_nodes && node->op == GGML_OP_RMS_NORM && single_use(node)) fop = fused_pair(node, cgraph->nodes[i + 1], &other);
+            if (fop == QMM_OP_RMS_NORM_MUL && node->ne[1] <= QMM_MATVEC_MAX_N && node->ne[2] == 1 && node->ne[3] == 1 && !GGML_MI355X_FUSE_OFF()) {
+                // every reader of the normed row a quantized MUL_MAT of one group (q/k/v, gate/up, output)?  Then no launch here:
+                // compute_mul_mat hands the norm to the mat-vec kernels, or materializes it if the group turns out smaller
+                const ggml_tensor * mul = cgraph->nodes[i + 1];
+                const auto * ri = info(mul);
+                const ggml_tensor * x = node->src[0];
+                int found = 0, first = -1;
+                for (int j = i + 2; j < n_nodes && j <= i + 2 + LOOKAHEAD && ri; ++j) {
+                    const ggml_tensor * t = cgraph->nodes[j];
+                    if (done[j] || is_noop(t)) continue;
+                    if (t->op == GGML_OP_MUL_MAT && !glue_op(t) && t->src[1] == mul && supports_mul_mat(t) && is_ours(t->src[0]) && !is_split(t->src[0]) &&
+                        t->src[0]->ne[2] == 1 && t->src[0]->ne[3] == 1) {
+                        if (first < 0) first = j;
+                        ++found;
+                    } else if (first < 0) {
+                        break;                                                         // something else reads or runs first: keep the graph's order
+                    }
+                }
+                const int64_t K = node->ne[0], N = node->ne[1];
+                if (ri && found == ri->uses && found >= 1 && found <= 4 && !(mul->flags & GGML_TENSOR_FLAG_OUTPUT) && x->nb[0] == 4 && x->nb[1] % 16 == 0 &&
+                    (uintptr_t) to_qt(x, ctx).data % 16 == 0 && (uintptr_t) other->data % 16 == 0 && K % 256 == 0 &&
+                    (size_t) N * K * 4 + (size_t) N * K * 11 / 8 + 4096 <= 150 * 1024) {
+                    ctx->pending_norm = { node, mul, other, found };
+                    done[i + 1] = 1;
+                    continue;
+                }
+            }
             if (fop) {
                 ggml_tensor * out = cgraph->nodes[i + 1];
                 ggml_tensor tmp = *out;                                              // dst of the pair, carrying the first node's op_params (eps)

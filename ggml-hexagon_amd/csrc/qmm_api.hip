@@ -35,7 +35,7 @@ static int launch_dequant(hipStream_t st, const void * w, int64_t rb, int64_t ro
 
 template <int T, int NTOK>
 static int launch_matvec_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K) {
-    const size_t lds = matvec_lds_bytes<T, NTOK>(K);
+    const size_t lds = matvec_lds_bytes<T, NTOK>(K) + (g.norm_w ? (size_t) NTOK * K * 4 : 0);
     if (lds > 160 * 1024) return fail(QMM_EUNSUPPORTED, "matvec: %d tokens x K=%d needs %zu B of LDS", NTOK, K, lds);
     auto kern = matvec_kernel<T, NTOK>;
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
@@ -53,7 +53,8 @@ static int launch_matvec_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, c
 
 template <int NTOK>
 static int launch_kmix_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K) {
-    const size_t lds = ((size_t) NTOK * K + (size_t) NTOK * (K / 256) * 4 + (size_t) NTOK * (K / 16) * 2 + 15) & ~(size_t) 15;
+    const size_t lds = kmix_lds_bytes(NTOK, K) + (g.norm_w ? (size_t) NTOK * K * 4 : 0);
+    if (lds > 160 * 1024) return fail(QMM_EUNSUPPORTED, "mixed-type matvec: %d tokens x K=%d needs %zu B of LDS", NTOK, K, lds);
     auto kern = matvec_kmix_kernel<NTOK>;
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     const int total = g.row_end[g.n - 1];
@@ -379,9 +380,22 @@ int qmm_quantize_act(qmm_ctx * c, int vt, const float * x, int64_t rows, int64_t
 
 // ------------------------------------------------------------------------------------------- mat-vec
 
-int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, const float * x, int64_t N, int64_t ldx, void * stream) {
+static int mul_mat_group_impl(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, const float * x, int64_t N, int64_t ldx, void * stream,
+                              const qmm_mv_extra * ex) {
     if (!c || !ws || nw <= 0) return fail(QMM_EINVAL, "qmm_mul_mat_group: bad arguments");
     if (N <= 0) return QMM_OK;
+    const float * norm_w = ex ? ex->norm_w : nullptr;
+    if (ex) {
+        if (N > QMM_MATVEC_MAX_N || nw > MV_MAX_GROUP) return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_group_ex: batches of <= %d tokens, <= %d matrices", QMM_MATVEC_MAX_N, MV_MAX_GROUP);
+        if (norm_w && ((uintptr_t) norm_w % 16 || ex->norm_eps < 0.0f)) return fail(QMM_EINVAL, "qmm_mul_mat_group_ex: norm weight must be 16-byte aligned, eps >= 0");
+        if (norm_w && (size_t) N * K * 4 + (size_t) N * K * 11 / 8 + 4096 > 150 * 1024) return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_group_ex: %lld rows of %lld do not fit LDS with the norm", (long long) N, (long long) K);
+    }
+    auto extras = [&](MatvecGroup & g, const int * src_index, int64_t n0) {      // residual pointers of the matrices in g, norm parameters
+        if (!ex) return;
+        for (int k = 0; k < g.n; ++k) g.res[k] = ex->residual[src_index[k]] ? ex->residual[src_index[k]] + n0 * g.ldd[k] : nullptr;
+        g.norm_w = norm_w;
+        g.norm_eps = ex->norm_eps;
+    };
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->s(stream);
     for (int i = 0; i < nw; ++i) {
@@ -399,14 +413,16 @@ int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, con
         if (kq && mixed && (size_t) N * K * 11 / 8 + 4096 <= 150 * 1024) {
             MatvecGroup g;
             memset(&g, 0, sizeof(g));
-            int rows = 0;
+            int rows = 0, idx[MV_MAX_GROUP];
             for (int i = 0; i < nw; ++i) {
                 g.w[i] = (const uint8_t *) ws[i].w;  g.dst[i] = ws[i].dst;  g.row_bytes[i] = ws[i].w_row_bytes;  g.ldd[i] = ws[i].ldd;
                 g.type[i] = ws[i].type;
                 rows += (int) ws[i].M;
                 g.row_end[i] = rows;
+                idx[i] = i;
             }
             g.n = nw;
+            extras(g, idx, 0);
             return launch_kmix(c, st, g, x, ldx, (int) K, (int) N);
         }
     }
@@ -416,9 +432,10 @@ int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, con
         while (i < nw) {
             MatvecGroup g;
             memset(&g, 0, sizeof(g));
-            int rows = 0, j = i;
+            int rows = 0, j = i, idx[MV_MAX_GROUP];
             while (j < nw && ws[j].type == ws[i].type && g.n < MV_MAX_GROUP) {
                 if (ws[j].M > 0) {
+                    idx[g.n] = j;
                     g.w[g.n] = (const uint8_t *) ws[j].w;
                     g.dst[g.n] = ws[j].dst;
                     g.row_bytes[g.n] = ws[j].w_row_bytes;
@@ -437,6 +454,7 @@ int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, con
                     const int nn = (int) ((N - n0) < n_at_once ? (N - n0) : n_at_once);
                     MatvecGroup gg = g;
                     for (int k = 0; k < gg.n; ++k) gg.dst[k] = g.dst[k] + n0 * g.ldd[k];
+                    extras(gg, idx, n0);
                     int rc = matvec_any(c, st, ws[i].type, gg, x + n0 * ldx, ldx, (int) K, nn);
                     if (rc) return rc;
                 }
@@ -461,6 +479,15 @@ int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, con
         i = j;
     }
     return QMM_OK;
+}
+
+int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, const float * x, int64_t N, int64_t ldx, void * stream) {
+    return mul_mat_group_impl(c, ws, nw, K, x, N, ldx, stream, nullptr);
+}
+
+int qmm_mul_mat_group_ex(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, const float * x, int64_t N, int64_t ldx, const qmm_mv_extra * ex,
+                         void * stream) {
+    return mul_mat_group_impl(c, ws, nw, K, x, N, ldx, stream, ex);
 }
 
 int qmm_mul_mat(qmm_ctx * c, int type, const void * w, int64_t rb, int64_t K, int64_t M,

@@ -28,7 +28,49 @@ struct MatvecGroup {
     int             row_end[MV_MAX_GROUP];   // cumulative row counts
     int             n;
     int             type[MV_MAX_GROUP];      // per matrix; read by matvec_kmix_kernel only
+    // what a caller that sees the whole layer can fold in (qmm_mul_mat_group_ex), all optional:
+    const float *   res[MV_MAX_GROUP];       // dst = W x + res (same row stride as dst): the residual add behind wo / ffn_down
+    const float *   norm_w;                  // x is rms_norm(x) * norm_w, formed while staging (attn_norm / ffn_norm in front of q/k/v, gate/up)
+    float           norm_eps;
 };
+
+// RMS_NORM * w of the NTOK activation rows into LDS (f32), by every workgroup: K floats per row are one or a few float4 per
+// thread, so this is two L2 reads and a block reduction in front of the quantizer instead of a launch of its own.
+// Same arithmetic as rms_norm_vec_kernel (qmm_ops.hip): per-thread sum of squares, wave butterfly, waves in order.
+template <int NTOK>
+__device__ __forceinline__ void stage_rms_norm(const float * __restrict__ x, int64_t ldx, int K, const float * __restrict__ w, float eps,
+                                               float * xs, float * red, int tid, int nthreads) {
+    const int lane = tid & (WAVE - 1), wave = tid / WAVE, nwaves = nthreads / WAVE;
+    const bool one_trip = K <= nthreads * 4;             // K = 4096 with 16 waves: the thread's slice stays in registers and
+    const int i0 = tid * 4;                              // the weight is requested before the reduction, not behind it
+    float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (one_trip && i0 < K) ww = *reinterpret_cast<const float4 *>(w + i0);
+#pragma unroll
+    for (int n = 0; n < NTOK; ++n) {
+        float sum = 0.0f;
+        float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = i0; i < K; i += nthreads * 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t) n * ldx + i);
+            if (one_trip) keep = v;
+            else *reinterpret_cast<float4 *>(xs + (size_t) n * K + i) = v;
+            sum += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        sum = wave_sum(sum);
+        __syncthreads();
+        if (lane == 0) red[wave] = sum;
+        __syncthreads();
+        float tot = red[0];
+        for (int k = 1; k < nwaves; ++k) tot += red[k];
+        const float scale = 1.0f / sqrtf(tot / (float) K + eps);
+        for (int i = i0; i < K; i += nthreads * 4) {
+            float4 v = one_trip ? keep : *reinterpret_cast<float4 *>(xs + (size_t) n * K + i);
+            if (!one_trip) ww = *reinterpret_cast<const float4 *>(w + i);
+            v.x = v.x * scale * ww.x; v.y = v.y * scale * ww.y; v.z = v.z * scale * ww.z; v.w = v.w * scale * ww.w;
+            *reinterpret_cast<float4 *>(xs + (size_t) n * K + i) = v;
+        }
+    }
+    __syncthreads();
+}
 
 template <int T> __host__ __device__ constexpr int act_block() { return Traits<T>::ACT == T_Q8_0 ? 32 : 256; }
 
@@ -65,20 +107,30 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
     const int total_rows = g.row_end[g.n - 1];
     const int W = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
 
-    auto locate = [&](int r, const uint8_t *& wrow, float *& drow, int64_t & ldd) {
+    auto locate = [&](int r, const uint8_t *& wrow, float *& drow, const float *& rrow, int64_t & ldd) {
         int i = 0, b0 = 0;
 #pragma unroll
         for (int k = 0; k < MV_MAX_GROUP - 1; ++k)
             if (k < g.n - 1 && r >= g.row_end[k]) { i = k + 1; b0 = g.row_end[k]; }
         wrow = g.w[i] + (int64_t) (r - b0) * g.row_bytes[i];
         drow = g.dst[i] + (r - b0);
+        rrow = g.res[i] ? g.res[i] + (r - b0) : nullptr;
         ldd  = g.ldd[i];
     };
 
-    const uint8_t * wrow; float * drow; int64_t ldd;
-    locate(min(gw, total_rows - 1), wrow, drow, ldd);
+    const uint8_t * wrow; float * drow; const float * rrow; int64_t ldd;
+    locate(min(gw, total_rows - 1), wrow, drow, rrow, ldd);
 
-    quantize_rows<ACT, MvUnit<T>::BSG, T>(x, ldx, NTOK, K, act_mode, aq, ad, ACT == T_Q8_K ? ab : nullptr, tid, blockDim.x);
+    const float * xq = x;
+    int64_t ldq = ldx;
+    if (g.norm_w) {                                       // the f32 rows sit behind the quantized fields (launcher sizes LDS for it)
+        __shared__ float red[16];
+        float * xs = reinterpret_cast<float *>(smem + matvec_lds_bytes<T, NTOK>(K));
+        stage_rms_norm<NTOK>(x, ldx, K, g.norm_w, g.norm_eps, xs, red, tid, blockDim.x);
+        xq = xs;
+        ldq = K;
+    }
+    quantize_rows<ACT, MvUnit<T>::BSG, T>(xq, ldq, NTOK, K, act_mode, aq, ad, ACT == T_Q8_K ? ab : nullptr, tid, blockDim.x);
     __syncthreads();
 
     for (int row = gw; row < total_rows; row += W) {
@@ -102,8 +154,8 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
             const float t = wave_sum(acc[n]);
             if (lane == n) out = t;
         }
-        if (lane < NTOK) drow[(int64_t) lane * ldd] = out;
-        if (row + W < total_rows) locate(row + W, wrow, drow, ldd);
+        if (lane < NTOK) drow[(int64_t) lane * ldd] = rrow ? out + rrow[(int64_t) lane * ldd] : out;
+        if (row + W < total_rows) locate(row + W, wrow, drow, rrow, ldd);
     }
 }
 
@@ -112,6 +164,10 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
 // 70B recipe's Q5_K/Q6_K mixes) in ONE launch: they all dot against the same Q8_K activations, so the staging is done once
 // (block sums per 16, which Q6_K needs and Q4_K/Q5_K add up in pairs; Q4_K's LDS order) and each wave picks the dot of the
 // matrix its row belongs to.  Saves the separate 3.4 MB launch (4.5 us at batch 1) of every such layer.
+__host__ __device__ inline size_t kmix_lds_bytes(int ntok, int K) {
+    return ((size_t) ntok * K + (size_t) ntok * (K / 256) * 4 + (size_t) ntok * (K / 16) * 2 + 15) & ~(size_t) 15;
+}
+
 template <int NTOK>
 __global__ void __launch_bounds__(1024)
 matvec_kmix_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t ldx, const int K, const int act_mode) {
@@ -127,7 +183,16 @@ matvec_kmix_kernel(const MatvecGroup g, const float * __restrict__ x, const int6
     const int total_rows = g.row_end[g.n - 1];
     const int W = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
 
-    quantize_rows<T_Q8_K, 16, T_Q4_K>(x, ldx, NTOK, K, act_mode, aq, ad, ab, tid, blockDim.x);
+    const float * xq = x;
+    int64_t ldq = ldx;
+    if (g.norm_w) {
+        __shared__ float red[16];
+        float * xs = reinterpret_cast<float *>(smem + kmix_lds_bytes(NTOK, K));
+        stage_rms_norm<NTOK>(x, ldx, K, g.norm_w, g.norm_eps, xs, red, tid, blockDim.x);
+        xq = xs;
+        ldq = K;
+    }
+    quantize_rows<T_Q8_K, 16, T_Q4_K>(xq, ldq, NTOK, K, act_mode, aq, ad, ab, tid, blockDim.x);
     __syncthreads();
 
     for (int row = gw; row < total_rows; row += W) {
@@ -137,6 +202,7 @@ matvec_kmix_kernel(const MatvecGroup g, const float * __restrict__ x, const int6
             if (k < g.n - 1 && row >= g.row_end[k]) { i = k + 1; b0 = g.row_end[k]; }
         const uint8_t * wrow = g.w[i] + (int64_t) (row - b0) * g.row_bytes[i];
         float * drow = g.dst[i] + (row - b0);
+        const float * rrow = g.res[i] ? g.res[i] + (row - b0) : nullptr;
         const int64_t ldd = g.ldd[i];
         const int type = __builtin_amdgcn_readfirstlane(g.type[i]);
         float acc[NTOK];
@@ -167,7 +233,7 @@ matvec_kmix_kernel(const MatvecGroup g, const float * __restrict__ x, const int6
             const float t = wave_sum(acc[n]);
             if (lane == n) out = t;
         }
-        if (lane < NTOK) drow[(int64_t) lane * ldd] = out;
+        if (lane < NTOK) drow[(int64_t) lane * ldd] = rrow ? out + rrow[(int64_t) lane * ldd] : out;
     }
 }
 

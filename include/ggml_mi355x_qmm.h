@@ -145,6 +145,20 @@ typedef struct qmm_weight {
 QMM_API int qmm_mul_mat_group(qmm_ctx * ctx, const qmm_weight * ws, int n_weights, int64_t K,
                               const float * x, int64_t N, int64_t ldx, void * stream);
 
+/* The same for a batch of <= QMM_MATVEC_MAX_N tokens with the two neighbours of the MUL_MAT in a transformer layer folded into the
+ * launch (both optional):
+ *   norm_w      x is rms_norm(x, norm_eps) * norm_w (one f32 row of K, 16-byte aligned), formed while the kernel stages its
+ *               activations: attn_norm in front of wq/wk/wv, ffn_norm in front of ffn_gate/ffn_up (llama.cpp build_norm);
+ *   residual[i] dst_i = W_i x + residual[i] (rows ldd_i apart, may be dst_i itself): the residual add behind wo / ffn_down. */
+typedef struct qmm_mv_extra {
+    const float * norm_w;
+    float         norm_eps;
+    const float * residual[4];
+} qmm_mv_extra;
+
+QMM_API int qmm_mul_mat_group_ex(qmm_ctx * ctx, const qmm_weight * ws, int n_weights, int64_t K,
+                                 const float * x, int64_t N, int64_t ldx, const qmm_mv_extra * extra, void * stream);
+
 /* GGML_OP_MUL_MAT_ID.
  *   as   [K, M, n_expert]  experts `expert_bytes` apart
  *   b    f32 [K, ne11, n_tokens]   element (k, i11, t) at b[t*b_nb2/4 + i11*b_nb1/4 + k]   (ne11 = n_used or 1)
