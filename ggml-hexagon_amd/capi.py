@@ -27,6 +27,10 @@ OPS_EXPORTS = [
 ]
 
 
+class QmmMvExtra(C.Structure):
+    _fields_ = [("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("residual", C.c_void_p * 4)]
+
+
 class QmmTensor(C.Structure):
     """qmm_tensor of include/ggml_mi355x_ops.h (the dsptensor of this boundary)"""
     _fields_ = [("data", C.c_void_p), ("type", C.c_int32), ("flags", C.c_int32), ("ne", C.c_int64 * 4), ("nb", C.c_int64 * 4),
@@ -100,6 +104,13 @@ def load_library() -> C.CDLL:
     lib.qmm_quantize_act.argtypes = [v, i32, v, i64, i64, i64, v, v, v, v]
     lib.qmm_mul_mat.argtypes = [v, i32, v, i64, i64, i64, v, i64, i64, v, i64, v]
     lib.qmm_mul_mat_group.argtypes = [v, C.POINTER(QmmWeight), i32, i64, v, i64, i64, v]
+    lib.qmm_mul_mat_group_ex.argtypes = [v, C.POINTER(QmmWeight), i32, i64, v, i64, i64, C.POINTER(QmmMvExtra), v]
+    P = C.POINTER(QmmTensor)
+    lib.qmm_op_supported.argtypes = [i32, P, P, P, P]
+    lib.qmm_op_compute.argtypes = [v, i32, P, P, P, P, v]
+    lib.qmm_op_add_rms_norm.argtypes = [v, P, P, P, P, P, C.c_float, v]
+    lib.qmm_attn_decode.argtypes = [v, P, P, P, P, P, C.c_float, v]
+    lib.qmm_rope_kv_store.argtypes = [v, P, P, P, P, P, P, P, P, v]
     lib.qmm_mul_mat_id.argtypes = [v, i32, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, i64, i64, v]
     lib.qmm_mul_mat_id_pair.argtypes = [v, i32, v, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, v, i64, i64, v]
     return lib
@@ -183,6 +194,26 @@ class Qmm:
             arr[i] = QmmWeight(w.data_ptr(), w.stride(0), w.shape[0], o.data_ptr(), o.stride(0), t)
         self._chk(self.lib.qmm_mul_mat_group(self.ctx, arr, len(weights), k, x.data_ptr(), x.shape[0], x.stride(0), self._stream()))
         return outs
+
+    def mul_mat_group_ex(self, weights, k, x, outs, norm_w=None, eps=0.0, residuals=None):
+        """qmm_mul_mat_group_ex: x -> rms_norm(x, eps) * norm_w while staging (optional), outs[i] = W_i x + residuals[i] (optional)"""
+        arr = (QmmWeight * len(weights))()
+        for i, ((t, w), o) in enumerate(zip(weights, outs)):
+            arr[i] = QmmWeight(w.data_ptr(), w.stride(0), w.shape[0], o.data_ptr(), o.stride(0), t)
+        ex = QmmMvExtra()
+        ex.norm_w = norm_w.data_ptr() if norm_w is not None else None
+        ex.norm_eps = eps
+        for i in range(4):
+            r = residuals[i] if residuals is not None and i < len(residuals) else None
+            ex.residual[i] = r.data_ptr() if r is not None else None
+        self._chk(self.lib.qmm_mul_mat_group_ex(self.ctx, arr, len(weights), k, x.data_ptr(), x.shape[0], x.stride(0), C.byref(ex),
+                                                self._stream()))
+        return outs
+
+    def op(self, op, dst, src0=None, src1=None, src2=None):
+        """qmm_op_compute on QmmTensor descriptors (include/ggml_mi355x_ops.h)"""
+        r = lambda t: C.byref(t) if t is not None else None
+        self._chk(self.lib.qmm_op_compute(self.ctx, op, r(src0), r(src1), r(src2), r(dst), self._stream()))
 
     def mul_mat_id(self, t, w, k, b, ids, out=None):
         """w uint8 [n_expert, M, row_bytes]; b f32 [n_tokens, ne11, K]; ids int32 [n_tokens, n_used] (row-strided view ok)

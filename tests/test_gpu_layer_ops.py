@@ -1,0 +1,183 @@
+"""GPU parity of the entry points that fold a layer's glue into fewer launches (include/ggml_mi355x_ops.h and
+qmm_mul_mat_group_ex), called through the C-ABI and checked against numpy restatements of the ggml CPU semantics
+(ggml-cpu.c:6254-6300 rms_norm, :8261-8352 soft_max, :8708-8893 rope; build_attn_mha src/llama-graph.cpp:1166-1203) and, for
+the quantized products, against the CPU oracle.  The per-op kernels behind qmm_op_compute are covered by the reference's own
+test-backend-ops (tests/test_gpu_backend_ops.py); these tests cover what that harness cannot express: the multi-node launches."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle.pyoracle import ACT_REF, Q4_0, Q4_K, Q6_K, TYPE_NAMES  # noqa: E402
+
+F32, F16, I32 = 0, 1, 26
+
+
+@pytest.fixture(scope="module")
+def qmm():
+    from ggml_hexagon_amd.capi import Qmm
+    q = Qmm(0)
+    yield q
+    q.close()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle.pyoracle import Oracle
+    return Oracle()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def T(t, type_, ne, nb=None, op_params=()):
+    from ggml_hexagon_amd.capi import QmmTensor
+    return QmmTensor.make(type_, ne, nb=nb, data=t.data_ptr(), op_params=op_params)
+
+
+def f2i(x):
+    return int(np.float32(x).view(np.int32))
+
+
+def rms_norm(x, w, eps):
+    x64 = x.astype(np.float64)
+    return (x * (1.0 / np.sqrt((x64 * x64).mean(axis=-1, keepdims=True) + eps)).astype(np.float32) * w).astype(np.float32)
+
+
+def rel_rms(got, want):
+    want = want.astype(np.float64)
+    return float(np.max(np.abs(got - want)) / max(np.sqrt(np.mean(want ** 2)), 1e-30))
+
+
+@pytest.mark.parametrize("n", [1, 3, 8])
+def test_mat_vec_with_norm_and_residual(qmm, oracle, n):
+    """qmm_mul_mat_group_ex: x -> rms_norm(x) * w formed in the kernel's staging phase, dst = W x + residual in the epilogue.
+    Against the oracle fed with the numpy-normed row (mat-vec bar 2e-5), for a same-type group, a mixed K-quant group and Q4_0."""
+    import ggml_hexagon_amd.synth as synth
+    rng = np.random.default_rng(100 + n)
+    for k, spec in ((4096, ((Q4_K, 320), (Q4_K, 64))), (4096, ((Q4_K, 256), (Q6_K, 96), (Q4_K, 33))), (1024, ((Q4_0, 200),))):
+        x = rng.normal(0, 1.5, (n, k)).astype(np.float32)
+        w = rng.normal(1, 0.1, k).astype(np.float32)
+        eps = 1e-5
+        xn = rms_norm(x, w, eps)
+        ws_np = [(t, synth.synth_weights(t, m, k, seed=m + t, sigma=0.25)) for t, m in spec]
+        ws = [(t, dev(a)) for t, a in ws_np]
+        res = [rng.normal(0, 1, (n, a.shape[0])).astype(np.float32) for _, a in ws_np]
+        outs = [torch.zeros((n, a.shape[0]), device="cuda") for _, a in ws_np]
+        if n * k * 4 + n * k * 11 // 8 + 4096 > 150 * 1024:      # the f32 rows do not fit LDS beside the quantized ones: refused, not emulated
+            from ggml_hexagon_amd.capi import QmmError
+            with pytest.raises(QmmError):
+                qmm.mul_mat_group_ex(ws, k, dev(x), outs, norm_w=dev(w), eps=eps)
+        else:
+            qmm.mul_mat_group_ex(ws, k, dev(x), outs, norm_w=dev(w), eps=eps, residuals=[dev(r) for r in res])
+            for (t, a), o, r in zip(ws_np, outs, res):
+                want = oracle.mul_mat(t, a, k, xn, ACT_REF) + r
+                assert rel_rms(o.cpu().numpy(), want) < 5e-5, (TYPE_NAMES[t], k, n)
+        # residual only, in place (dst is the residual buffer): the wo / ffn_down form
+        acc = [dev(r) for r in res]
+        qmm.mul_mat_group_ex(ws[:1], k, dev(x), acc[:1], residuals=acc[:1])
+        assert rel_rms(acc[0].cpu().numpy(), oracle.mul_mat(ws_np[0][0], ws_np[0][1], k, x, ACT_REF) + res[0]) < 2e-5
+
+
+def test_add_rms_norm_two_results(qmm):
+    from ggml_hexagon_amd import capi
+    rng = np.random.default_rng(5)
+    for rows, k in ((1, 4096), (7, 4096), (300, 1024), (2, 8192)):
+        a, b = rng.normal(0, 1, (rows, k)).astype(np.float32), rng.normal(0, 2, (rows, k)).astype(np.float32)
+        w = rng.normal(1, 0.1, k).astype(np.float32)
+        da, db, dw = dev(a), dev(b), dev(w)
+        s, y = torch.empty_like(da), torch.empty_like(da)
+        r = lambda t: capi.C.byref(t)
+        qmm._chk(qmm.lib.qmm_op_add_rms_norm(qmm.ctx, r(T(da, F32, [k, rows])), r(T(db, F32, [k, rows])), r(T(dw, F32, [k])),
+                                             r(T(s, F32, [k, rows])), r(T(y, F32, [k, rows])), 1e-6, qmm._stream()))
+        assert np.array_equal(s.cpu().numpy(), a + b)
+        assert rel_rms(y.cpu().numpy(), rms_norm(a + b, w, 1e-6)) < 2e-6
+
+
+def rope_ref(x, pos, n_dims, theta_scale):
+    """normal-mode rope of x [n_tok, n_head, d] with the CPU's repeated f32 multiply for theta (ggml-cpu.c:8634-8648)"""
+    out = x.copy()
+    for t in range(x.shape[0]):
+        theta = np.float32(pos[t])
+        for p in range(n_dims // 2):
+            c, s = np.float32(np.cos(np.float64(theta))), np.float32(np.sin(np.float64(theta)))
+            x0, x1 = x[t, :, 2 * p].copy(), x[t, :, 2 * p + 1].copy()
+            out[t, :, 2 * p] = x0 * c - x1 * s
+            out[t, :, 2 * p + 1] = x0 * s + x1 * c
+            theta = np.float32(theta * theta_scale)
+    return out
+
+
+@pytest.mark.parametrize("n_tok", [1, 5])
+def test_rope_kv_store_one_launch(qmm, n_tok):
+    """rope(q) -> f32, rope(k) -> f16 K cache rows, v -> transposed f16 V cache, as build_attn lays them out"""
+    from ggml_hexagon_amd import capi
+    rng = np.random.default_rng(7 + n_tok)
+    d, h, hk, n_ctx, kv_head = 128, 8, 2, 96, 17
+    q = rng.normal(0, 1, (n_tok, h, d)).astype(np.float32)
+    k = rng.normal(0, 1, (n_tok, hk, d)).astype(np.float32)
+    v = rng.normal(0, 1, (n_tok, hk * d)).astype(np.float32)
+    pos = np.arange(kv_head, kv_head + n_tok, dtype=np.int32)
+    freq_base = 10000.0
+    theta_scale = np.float32(np.float32(freq_base) ** np.float32(-2.0 / d))
+    dq, dk, dv, dpos = dev(q), dev(k), dev(v), dev(pos)
+    q_out = torch.empty_like(dq)
+    k_cache = torch.zeros((n_ctx, hk * d), dtype=torch.float16, device="cuda")
+    v_cache = torch.zeros((hk * d, n_ctx), dtype=torch.float16, device="cuda")
+    params = [0, d, 0, 0, 8192, f2i(freq_base), f2i(1.0), f2i(0.0), f2i(1.0), f2i(32.0), f2i(1.0)]
+    tq = T(dq, F32, [d, h, n_tok])
+    tqo = T(q_out, F32, [d, h, n_tok], op_params=params)
+    tk = T(dk, F32, [d, hk, n_tok])
+    tkd = capi.QmmTensor.make(F16, [d, hk, n_tok], data=k_cache.data_ptr() + kv_head * hk * d * 2)
+    tv = capi.QmmTensor.make(F32, [n_tok, hk * d], nb=[hk * d * 4, 4, 4 * n_tok * hk * d, 4 * n_tok * hk * d], data=dv.data_ptr())   # v_cur^T
+    tvd = capi.QmmTensor.make(F16, [n_tok, hk * d], nb=[2, n_ctx * 2, n_ctx * 2 * hk * d, n_ctx * 2 * hk * d], data=v_cache.data_ptr() + kv_head * 2)
+    r = lambda t: capi.C.byref(t)
+    qmm._chk(qmm.lib.qmm_rope_kv_store(qmm.ctx, r(tq), r(T(dpos, I32, [n_tok])), None, r(tqo), r(tk), r(tkd), r(tv), r(tvd), qmm._stream()))
+    want_q = rope_ref(q, pos, d, theta_scale)
+    want_k = rope_ref(k, pos, d, theta_scale).reshape(n_tok, hk * d).astype(np.float16)
+    assert rel_rms(q_out.cpu().numpy(), want_q) < 2e-5
+    kc = k_cache.cpu().numpy()
+    assert np.max(np.abs(kc[kv_head:kv_head + n_tok].astype(np.float32) - want_k.astype(np.float32))) < 4e-3
+    assert not kc[:kv_head].any() and not kc[kv_head + n_tok:].any()
+    vc = v_cache.cpu().numpy()
+    assert np.array_equal(vc[:, kv_head:kv_head + n_tok], v.T.astype(np.float16))
+    assert not vc[:, :kv_head].any() and not vc[:, kv_head + n_tok:].any()
+
+
+@pytest.mark.parametrize("n_tok,n_kv,d", [(1, 640, 128), (3, 96, 128), (1, 32, 64), (8, 1024, 128)])
+def test_attn_decode_one_launch(qmm, n_tok, n_kv, d):
+    """KQ -> soft_max(scale, mask) -> KQV -> merged heads, grouped-query, against f64 numpy with the CPU's f16 roundings of q and p"""
+    from ggml_hexagon_amd import capi
+    rng = np.random.default_rng(n_kv + n_tok)
+    h, hk, n_ctx = 8, 2, n_kv + 64
+    q = rng.normal(0, 1, (h, n_tok, d)).astype(np.float32)
+    kc = rng.normal(0, 1, (n_ctx, hk, d)).astype(np.float16)
+    vc = rng.normal(0, 1, (hk, d, n_ctx)).astype(np.float16)
+    mask = np.zeros((64, n_kv), np.float32)
+    for t in range(n_tok):
+        mask[t, n_kv - (n_tok - 1 - t) * 3:] = -np.inf          # each token sees a different prefix
+    mask[:, 5] = -np.inf
+    scale = 1.0 / np.sqrt(d)
+    dq, dk, dv, dm = dev(q.transpose(1, 0, 2)), dev(kc), dev(vc), dev(mask)          # q_cur layout [n_tok, h, d], permuted view below
+    out = torch.empty((n_tok, h * d), device="cuda")
+    tq = capi.QmmTensor.make(F32, [d, n_tok, h], nb=[4, h * d * 4, d * 4, n_tok * h * d * 4], data=dq.data_ptr())
+    tk = capi.QmmTensor.make(F16, [d, n_kv, hk], nb=[2, hk * d * 2, d * 2, n_ctx * hk * d * 2], data=dk.data_ptr())
+    tv = capi.QmmTensor.make(F16, [n_kv, d, hk], nb=[2, n_ctx * 2, n_ctx * d * 2, n_ctx * d * hk * 2], data=dv.data_ptr())
+    tm = capi.QmmTensor.make(F32, [n_kv, 64], data=dm.data_ptr())
+    td = capi.QmmTensor.make(F32, [h * d, n_tok], data=out.data_ptr())
+    r = lambda t: capi.C.byref(t)
+    qmm._chk(qmm.lib.qmm_attn_decode(qmm.ctx, r(tq), r(tk), r(tv), r(tm), r(td), scale, qmm._stream()))
+    got = out.cpu().numpy().reshape(n_tok, h, d)
+    qh = q.astype(np.float16).astype(np.float64)
+    for hh in range(h):
+        g = hh // (h // hk)
+        s = qh[hh] @ kc[:n_kv, g].astype(np.float64).T * np.float32(scale) + mask[:n_tok]
+        p = np.exp(s - s.max(axis=1, keepdims=True))
+        p = (p / p.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float16).astype(np.float64)
+        want = p @ vc[g, :, :n_kv].astype(np.float64).T
+        # p is rounded to f16 (as the CPU's F16 vec_dot does): an f32-vs-f64 difference in exp / sum can flip such a rounding,
+        # one flip is 2^-11 of one probability
+        assert rel_rms(got[:, hh], want) < 5e-4, (hh, n_tok, n_kv)
