@@ -651,6 +651,8 @@ int glue_op(const ggml_tensor * node) {
         case GGML_OP_SOFT_MAX: return QMM_OP_SOFT_MAX;
         case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: return QMM_OP_CPY;
         case GGML_OP_GET_ROWS: return QMM_OP_GET_ROWS;
+        case GGML_OP_ARGSORT:  return QMM_OP_ARGSORT;
+        case GGML_OP_SUM_ROWS: return QMM_OP_SUM_ROWS;
         case GGML_OP_MUL_MAT:  return node->src[0] && (node->src[0]->type == GGML_TYPE_F16 || node->src[0]->type == GGML_TYPE_F32) ? QMM_OP_MUL_MAT_F : 0;
         case GGML_OP_UNARY:
             switch (ggml_get_unary_op(node)) {

@@ -429,6 +429,42 @@ get_rows_q_kernel(const uint8_t * __restrict__ x, const char * __restrict__ ids,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ ARGSORT, SUM_ROWS
+// The two small ops of the MoE router (build_moe_ffn, src/llama-graph.cpp:842-858: ggml_top_k = argsort + view, ggml_sum_rows
+// for the weight normalisation), so that a Mixtral layer stays one split.
+// ggml_compute_forward_argsort_f32 (ggml-cpu.c:10199-10236) orders indices by value; here by rank: element i goes to the
+// position "number of elements that sort before it" (ties by index), the same permutation whenever the values are distinct.
+__global__ void __launch_bounds__(256)
+argsort_kernel(const char * __restrict__ x, char * __restrict__ y, const Shape sx, const Shape sy, const int desc) {
+    uint32_t i1, i2, i3;
+    row_coords(blockIdx.x, (uint32_t) sx.ne[1], (uint32_t) sx.ne[2], i1, i2, i3);
+    const float * px = (const float *) (x + i1 * sx.nb[1] + i2 * sx.nb[2] + i3 * sx.nb[3]);
+    int32_t *     py = (int32_t *) (y + i1 * sy.nb[1] + i2 * sy.nb[2] + i3 * sy.nb[3]);
+    const uint32_t n = (uint32_t) sx.ne[0];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const float v = px[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const float u = px[j];
+            rank += (desc ? u > v : u < v) || (u == v && j < i);
+        }
+        py[rank] = (int32_t) i;
+    }
+}
+// ggml_compute_forward_sum_rows_f32 (ggml-cpu.c): dst[0, i1, i2, i3] = sum over i0; one wave per row
+__global__ void __launch_bounds__(256)
+sum_rows_kernel(const char * __restrict__ x, char * __restrict__ y, const Shape sx, const Shape sy, const uint32_t rows) {
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    uint32_t i1, i2, i3;
+    row_coords(row, (uint32_t) sx.ne[1], (uint32_t) sx.ne[2], i1, i2, i3);
+    const float * px = (const float *) (x + i1 * sx.nb[1] + i2 * sx.nb[2] + i3 * sx.nb[3]);
+    float s = 0.0f;
+    for (uint32_t i = lane; i < (uint32_t) sx.ne[0]; i += 64) s += px[i];
+    s = wave_sum(s);
+    if (lane == 0) *(float *) (y + i1 * sy.nb[1] + i2 * sy.nb[2] + i3 * sy.nb[3]) = s;
+}
+
 // ------------------------------------------------------------------------------------------------ MUL_MAT, F16 / F32 src0
 // ggml_compute_forward_mul_mat with a non-quantized src0 (ggml-cpu.c:6745-6937): the KQ and KQV products of
 // build_attn_mha (src/llama-graph.cpp:1126-1213), whose src0 is a strided view of the F16 KV cache, and small F32 matrices
@@ -848,6 +884,10 @@ int qmm_op_supported(int op, const qmm_tensor * a, const qmm_tensor * b, const q
         case QMM_OP_CPY:          return sup_cpy(a, d);
         case QMM_OP_GET_ROWS:     return sup_get_rows(a, b, d);
         case QMM_OP_MUL_MAT_F:    return sup_mul_mat_f(a, b, d);
+        case QMM_OP_ARGSORT:      return a && d && a->type == G_F32 && d->type == G_I32 && same_shape(a, d) && dense_rows(a) && dense_rows(d) &&
+                                         nelements(a) > 0 && a->ne[0] <= 4096 && nrows(a) < ((int64_t) 1 << 31) && (d->op_params[0] == 0 || d->op_params[0] == 1);
+        case QMM_OP_SUM_ROWS:     return a && d && a->type == G_F32 && d->type == G_F32 && dense_rows(a) && d->ne[0] == 1 && d->ne[1] == a->ne[1] &&
+                                         d->ne[2] == a->ne[2] && d->ne[3] == a->ne[3] && nelements(a) > 0 && nrows(a) < ((int64_t) 1 << 31);
         default:                  return 0;
     }
 }
@@ -925,6 +965,17 @@ int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * a, const qmm_tensor
             return QMM_OK;
         }
         case QMM_OP_MUL_MAT_F: return launch_mul_mat_f(st, a, b, d);
+        case QMM_OP_ARGSORT:
+            hipLaunchKernelGGL(argsort_kernel, dim3((unsigned) nrows(a)), dim3(256), 0, st, (const char *) a->data, (char *) d->data, shape_of(a), shape_of(d),
+                               d->op_params[0]);
+            HIP_TRY(hipGetLastError());
+            return QMM_OK;
+        case QMM_OP_SUM_ROWS: {
+            const uint32_t rows = (uint32_t) nrows(a);
+            hipLaunchKernelGGL(sum_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const char *) a->data, (char *) d->data, shape_of(a), shape_of(d), rows);
+            HIP_TRY(hipGetLastError());
+            return QMM_OK;
+        }
         default: return fail(QMM_EUNSUPPORTED, "qmm_op_compute: unknown op %d", op);
     }
 }

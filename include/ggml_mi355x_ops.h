@@ -44,6 +44,9 @@ enum qmm_op {
     /* fused pairs the plugin forms from consecutive nodes */
     QMM_OP_RMS_NORM_MUL,      /* dst = rms_norm(src0) * src1, src1 one f32 row broadcast over all rows */
     QMM_OP_SILU_MUL,          /* dst = silu(src0) * src1, same shapes, contiguous (SwiGLU of build_ffn) */
+    /* the MoE router (build_moe_ffn) */
+    QMM_OP_ARGSORT,           /* i32 indices that order each row; op_params[0] = 0 ascending, 1 descending (ggml_top_k = this + a view) */
+    QMM_OP_SUM_ROWS,          /* dst [1, ne1, ne2, ne3] = row sums */
     QMM_OP_COUNT
 };
 
