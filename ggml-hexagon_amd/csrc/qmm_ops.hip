@@ -274,6 +274,49 @@ soft_max_kernel(const float * __restrict__ x, const void * __restrict__ mask, fl
     for (uint32_t i = threadIdx.x; i < nc; i += 256) py[i] = v[i] * inv;
 }
 
+// Rows of up to 1024 values (attention over a prompt of that length): one WAVE per row, the row in registers (float4 per
+// lane and trip), reductions on the wave only: no LDS, no barrier, four rows per workgroup.  f32 mask, no ALiBi.
+template <int V4>      // float4 per lane: the row has at most 256 * V4 values
+__global__ void __launch_bounds__(256)
+soft_max_wave_kernel(const float * __restrict__ x, const float * __restrict__ mask, float * __restrict__ y, const uint32_t nc, const uint32_t ne01,
+                     const uint32_t rows, const float scale) {
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float4 * px = (const float4 *) (x + (size_t) row * nc);
+    const float4 * pm = mask ? (const float4 *) (mask + (size_t) (row % ne01) * nc) : nullptr;
+    float4 *       py = (float4 *) (y + (size_t) row * nc);
+    const uint32_t n4 = nc / 4;
+    float4 v[V4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < V4; ++j) {
+        const uint32_t i = lane + 64 * j;
+        if (i < n4) {
+            float4 t = px[i];
+            t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
+            if (pm) { const float4 m = pm[i]; t.x += m.x; t.y += m.y; t.z += m.z; t.w += m.w; }
+            v[j] = t;
+            mx = fmaxf(fmaxf(mx, fmaxf(t.x, t.y)), fmaxf(t.z, t.w));
+        } else {
+            v[j] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < V4; ++j) {
+        v[j].x = expf(v[j].x - mx); v[j].y = expf(v[j].y - mx); v[j].z = expf(v[j].z - mx); v[j].w = expf(v[j].w - mx);
+        sum += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < V4; ++j) {
+        const uint32_t i = lane + 64 * j;
+        if (i < n4) py[i] = make_float4(v[j].x * inv, v[j].y * inv, v[j].z * inv, v[j].w * inv);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ ROPE
 // ggml_compute_forward_rope_f32 (ggml-cpu.c:8708-8893) with rope_yarn / ggml_rope_cache_init (:8610-8648): modes "normal"
 // (pairs (2p, 2p+1)) and NEOX (pairs (p, p + n_dims/2)); channels >= n_dims are copied.  theta is built by the same
@@ -938,6 +981,16 @@ int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * a, const qmm_tensor
             const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
             const size_t lds = nc <= 8192 ? (size_t) nc * 4 : 0;
             const dim3 grid((unsigned) nrows(d));
+            const uint32_t rows = (uint32_t) nrows(d);
+            if (max_bias == 0.0f && (!b || b->type == G_F32) && nc % 4 == 0 && nc <= 1024 && rows >= 1024 && (uintptr_t) a->data % 16 == 0 &&
+                (uintptr_t) d->data % 16 == 0 && (!b || (uintptr_t) b->data % 16 == 0)) {
+                const float * m = b ? (const float *) b->data : nullptr;
+                if (nc <= 256)      hipLaunchKernelGGL((soft_max_wave_kernel<1>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float *) a->data, m, (float *) d->data, nc, ne01, rows, scale);
+                else if (nc <= 512) hipLaunchKernelGGL((soft_max_wave_kernel<2>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float *) a->data, m, (float *) d->data, nc, ne01, rows, scale);
+                else                hipLaunchKernelGGL((soft_max_wave_kernel<4>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float *) a->data, m, (float *) d->data, nc, ne01, rows, scale);
+                HIP_TRY(hipGetLastError());
+                return QMM_OK;
+            }
             if (b && b->type == G_F16)
                 hipLaunchKernelGGL((soft_max_kernel<true>), grid, dim3(256), lds, st, (const float *) a->data, (const void *) b->data, (float *) d->data,
                                    nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
