@@ -907,8 +907,38 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                     }
                 }
             }
-            if (node->op == GGML_OP_ROPE && node->ne[2] <= 8 && !GGML_MI355X_FUSE_OFF()) {
-                // rope(q) with, from further down the graph, rope(k) -> K cache and v -> V cache (build_attn's two ggml_cpy): one launch.
+            if (gop == QMM_OP_MUL_MAT_F && node->src[0]->type == GGML_TYPE_F16 && single_use(node) && !GGML_MI355X_FUSE_OFF() && !done[i]) {
+                // kqv -> permute(0, 2, 1, 3) -> cont (build_attn_mha's head merge) at any batch size: the product is written
+                // straight into the cont's layout (dst strides of dims 1 and 2 swapped), the copy never runs
+                int jp = i + 1;
+                while (jp < n_nodes && (cgraph->nodes[jp]->op == GGML_OP_RESHAPE || cgraph->nodes[jp]->op == GGML_OP_VIEW)) ++jp;
+                int jc = jp + 1;
+                while (jc < n_nodes && (cgraph->nodes[jc]->op == GGML_OP_RESHAPE || cgraph->nodes[jc]->op == GGML_OP_VIEW)) ++jc;
+                if (jc < n_nodes) {
+                    const ggml_tensor * pm = cgraph->nodes[jp], * ct = cgraph->nodes[jc];
+                    if (pm->op == GGML_OP_PERMUTE && pm->src[0] == node && ct->op == GGML_OP_CONT && ct->src[0] == pm && !done[jc] &&
+                        pm->ne[0] == node->ne[0] && pm->ne[1] == node->ne[2] && pm->ne[2] == node->ne[1] && node->ne[3] == 1 &&
+                        ct->type == GGML_TYPE_F32 && ggml_is_contiguous(ct) && ggml_nelements(ct) == ggml_nelements(node)) {
+                        qmm_tensor d = to_qt(node, ctx);
+                        d.data = ct->data;                                            // element (d, n, h) of kqv = element (d, h, n) of the merged result
+                        d.nb[1] = (int64_t) node->ne[0] * node->ne[2] * 4;
+                        d.nb[2] = (int64_t) node->ne[0] * 4;
+                        d.nb[3] = (int64_t) ggml_nbytes(ct);
+                        const qmm_tensor a = to_qt(node->src[0], ctx), b = to_qt(node->src[1], ctx);
+                        if (qmm_op_supported(QMM_OP_MUL_MAT_F, &a, &b, nullptr, &d)) {
+                            if (qmm_op_compute(ctx->dev->qmm, QMM_OP_MUL_MAT_F, &a, &b, nullptr, &d, qmm_stream(ctx->dev->qmm))) {
+                                GGML_LOG_ERROR("MI355X MUL_MAT(%s) into merged heads: %s\n", node->name, qmm_last_error());
+                                return GGML_STATUS_FAILED;
+                            }
+                            done[jc] = 1;
+                            continue;
+                        }
+                    }
+                }
+            }
+            if (node->op == GGML_OP_ROPE && !GGML_MI355X_FUSE_OFF()) {
+                // rope(q) with, from further down the graph, rope(k) -> K cache and v -> V cache (build_attn's two ggml_cpy): one launch
+                // (any batch size: at 512 tokens 29 us of four launches become one, pp512 31.2k -> 32.0k).
                 // Their inputs must exist already (k and v were hoisted into the q/k/v group); the cache is not compute-buffer
                 // memory, so storing early cannot collide with anything in between.
                 auto ready = [&](const ggml_tensor * t) {                            // was t's root produced before this point?
