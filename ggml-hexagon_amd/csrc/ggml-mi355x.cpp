@@ -878,8 +878,9 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                     }
                 }
             }
-            if (gop == QMM_OP_MUL_MAT_F && node->src[0]->type == GGML_TYPE_F16 && node->src[1]->ne[1] <= 8 && single_use(node) && !GGML_MI355X_FUSE_OFF()) {
-                // kq -> soft_max -> kqv -> permute -> cont (build_attn_mha) for a few tokens: one launch
+            if (gop == QMM_OP_MUL_MAT_F && node->src[0]->type == GGML_TYPE_F16 && single_use(node) && !GGML_MI355X_FUSE_OFF()) {
+                // kq -> soft_max -> kqv -> permute -> cont (build_attn_mha): one launch, for a few tokens (qmm_attn_decode) and for prompt
+                // batches whose scores fit LDS (qmm_attn_prefill)
                 int idx[4], k = 0;
                 for (int j = i + 1; j < n_nodes && j <= i + 8 && k < 4; ++j) {
                     const ggml_tensor * t = cgraph->nodes[j];
@@ -896,8 +897,10 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                         pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv && pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] &&
                         pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm) {
                         const qmm_tensor q = to_qt(node->src[1], ctx), kk = to_qt(node->src[0], ctx), v = to_qt(kqv->src[0], ctx), m = to_qt(sm->src[1], ctx), d = to_qt(ct, ctx);
-                        if (qmm_attn_decode_supported(&q, &kk, &v, &m, &d)) {
-                            if (qmm_attn_decode(ctx->dev->qmm, &q, &kk, &v, &m, &d, scale, qmm_stream(ctx->dev->qmm))) {
+                        const bool few = qmm_attn_decode_supported(&q, &kk, &v, &m, &d) != 0;
+                        if (few || qmm_attn_prefill_supported(&q, &kk, &v, &m, &d)) {
+                            if (few ? qmm_attn_decode(ctx->dev->qmm, &q, &kk, &v, &m, &d, scale, qmm_stream(ctx->dev->qmm))
+                                    : qmm_attn_prefill(ctx->dev->qmm, &q, &kk, &v, &m, &d, scale, qmm_stream(ctx->dev->qmm))) {
                                 GGML_LOG_ERROR("MI355X attention(%s): %s\n", node->name, qmm_last_error());
                                 return GGML_STATUS_FAILED;
                             }

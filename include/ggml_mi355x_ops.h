@@ -78,6 +78,14 @@ QMM_API int qmm_attn_decode_supported(const qmm_tensor * q, const qmm_tensor * k
 QMM_API int qmm_attn_decode(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask,
                             const qmm_tensor * dst, float scale, void * stream);
 
+/* The same chain for a prompt batch of any size whose scores fit LDS (n_kv <= 512, a multiple of 32; D = Dv in {64, 128}): one
+ * workgroup per (64 tokens, head) keeps the 64 x n_kv score tile in LDS between the two MFMA products, so the f32 score tensor
+ * (33 MB per layer at 512 x 512 x 32 heads) never exists.  Same operands and result layout as qmm_attn_decode. */
+QMM_API int qmm_attn_prefill_supported(const qmm_tensor * q, const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask,
+                                       const qmm_tensor * dst);
+QMM_API int qmm_attn_prefill(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask,
+                             const qmm_tensor * dst, float scale, void * stream);
+
 /* What follows the q / k / v projections of a few-token batch in build_attn (src/llama-graph.cpp:1306-1365), in one launch:
  *   q_dst = rope(q) (f32; q_dst carries the ROPE node's op_params), k_dst = (f16) rope(k) straight into the K cache view,
  *   v_dst = (f16) v into the (transposed) V cache view, element i of v (in v's index order) to element i of v_dst, as CPY does.

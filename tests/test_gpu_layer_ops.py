@@ -181,3 +181,40 @@ def test_attn_decode_one_launch(qmm, n_tok, n_kv, d):
         # p is rounded to f16 (as the CPU's F16 vec_dot does): an f32-vs-f64 difference in exp / sum can flip such a rounding,
         # one flip is 2^-11 of one probability
         assert rel_rms(got[:, hh], want) < 5e-4, (hh, n_tok, n_kv)
+
+
+@pytest.mark.parametrize("n_tok,n_kv,d", [(512, 512, 128), (70, 96, 128), (33, 64, 64), (200, 480, 128)])
+def test_attn_prefill_one_launch(qmm, n_tok, n_kv, d):
+    """the same chain for a prompt batch with the scores held in LDS (n_kv <= 512): ragged token tiles, n_kv not a multiple of
+    the 64-row K tile, D = 64 and 128, grouped-query, causal-style mask"""
+    from ggml_hexagon_amd import capi
+    rng = np.random.default_rng(n_kv * 7 + n_tok)
+    h, hk, n_ctx = 8, 2, n_kv + 32
+    q = rng.normal(0, 1, (h, n_tok, d)).astype(np.float32)
+    kc = rng.normal(0, 1, (n_ctx, hk, d)).astype(np.float16)
+    vc = rng.normal(0, 1, (hk, d, n_ctx)).astype(np.float16)
+    n_pad = (n_tok + 63) // 64 * 64
+    mask = np.zeros((n_pad, n_kv), np.float32)
+    for t in range(n_tok):
+        mask[t, min(n_kv, n_kv - n_tok + t + 1):] = -np.inf           # token t sees the prefix that ends at its own position
+    scale = 1.0 / np.sqrt(d)
+    dq, dk, dv, dm = dev(q.transpose(1, 0, 2)), dev(kc), dev(vc), dev(mask)
+    out = torch.empty((n_tok, h * d), device="cuda")
+    tq = capi.QmmTensor.make(F32, [d, n_tok, h], nb=[4, h * d * 4, d * 4, n_tok * h * d * 4], data=dq.data_ptr())
+    tk = capi.QmmTensor.make(F16, [d, n_kv, hk], nb=[2, hk * d * 2, d * 2, n_ctx * hk * d * 2], data=dk.data_ptr())
+    tv = capi.QmmTensor.make(F16, [n_kv, d, hk], nb=[2, n_ctx * 2, n_ctx * d * 2, n_ctx * d * hk * 2], data=dv.data_ptr())
+    tm = capi.QmmTensor.make(F32, [n_kv, n_pad], data=dm.data_ptr())
+    td = capi.QmmTensor.make(F32, [h * d, n_tok], data=out.data_ptr())
+    r = lambda t: capi.C.byref(t)
+    qmm._chk(qmm.lib.qmm_attn_prefill(qmm.ctx, r(tq), r(tk), r(tv), r(tm), r(td), scale, qmm._stream()))
+    got = out.cpu().numpy().reshape(n_tok, h, d)
+    qh = q.astype(np.float16).astype(np.float64)
+    for hh in range(h):
+        g = hh // (h // hk)
+        s = qh[hh] @ kc[:n_kv, g].astype(np.float64).T * np.float32(scale) + mask[:n_tok]
+        p = np.exp(s - s.max(axis=1, keepdims=True))
+        p = (p / p.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float16).astype(np.float64)
+        want = p @ vc[g, :, :n_kv].astype(np.float64).T
+        # tokens early in the prompt have few, large probabilities: one flipped f16 rounding of p ~ 0.5 moves an output by 2.4e-4
+        assert rel_rms(got[:, hh], want) < 2e-3, (hh, n_tok, n_kv)
+        assert np.sqrt(np.mean((got[:, hh] - want) ** 2) / np.mean(want ** 2)) < 1e-4
