@@ -33,11 +33,17 @@ static int launch_dequant(hipStream_t st, const void * w, int64_t rb, int64_t ro
     return QMM_OK;
 }
 
+static bool group_has_extras(const MatvecGroup & g) {
+    bool ex = g.norm_w != nullptr;
+    for (int i = 0; i < g.n; ++i) ex = ex || g.res[i] != nullptr;
+    return ex;
+}
+
 template <int T, int NTOK>
 static int launch_matvec_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K) {
     const size_t lds = matvec_lds_bytes<T, NTOK>(K) + (g.norm_w ? (size_t) NTOK * K * 4 : 0);
     if (lds > 160 * 1024) return fail(QMM_EUNSUPPORTED, "matvec: %d tokens x K=%d needs %zu B of LDS", NTOK, K, lds);
-    auto kern = matvec_kernel<T, NTOK>;
+    auto kern = group_has_extras(g) ? matvec_kernel<T, NTOK, true> : matvec_kernel<T, NTOK, false>;
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     const int total = g.row_end[g.n - 1];
     // one block per CU (the activation vector is quantized once per CU); 16 waves per block unless there are
@@ -55,7 +61,7 @@ template <int NTOK>
 static int launch_kmix_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K) {
     const size_t lds = kmix_lds_bytes(NTOK, K) + (g.norm_w ? (size_t) NTOK * K * 4 : 0);
     if (lds > 160 * 1024) return fail(QMM_EUNSUPPORTED, "mixed-type matvec: %d tokens x K=%d needs %zu B of LDS", NTOK, K, lds);
-    auto kern = matvec_kmix_kernel<NTOK>;
+    auto kern = group_has_extras(g) ? matvec_kmix_kernel<NTOK, true> : matvec_kmix_kernel<NTOK, false>;
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     const int total = g.row_end[g.n - 1];
     int nw = (total + c->cus - 1) / c->cus;

@@ -91,7 +91,9 @@ template <int T, int NTOK> __host__ __device__ inline size_t matvec_lds_bytes(in
 // slices' loads in flight per wave on K = 14336 rows: 11.5 -> 14.7 us; two Q4_0 blocks per lane and slice: 9.4 MB
 // 6.2 -> 5.8 us but the 7B pass 743 -> 724 tok/s; nontemporal weight loads: 66 MB 15.3 -> 18.5 us.  Every variant that
 // widens a wave's window of outstanding loads loses on the long streams.)
-template <int T, int NTOK>
+// EX: the instantiation that honours g.res / g.norm_w (qmm_mul_mat_group_ex); the plain one compiles them away, so the hot
+// path of bench.py is the kernel it was before those fields existed (with them as run-time branches: 9.17 -> 9.50 us per launch)
+template <int T, int NTOK, bool EX>
 __global__ void __launch_bounds__(1024)
 matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t ldx, const int K, const int act_mode) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -114,7 +116,7 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
             if (k < g.n - 1 && r >= g.row_end[k]) { i = k + 1; b0 = g.row_end[k]; }
         wrow = g.w[i] + (int64_t) (r - b0) * g.row_bytes[i];
         drow = g.dst[i] + (r - b0);
-        rrow = g.res[i] ? g.res[i] + (r - b0) : nullptr;
+        rrow = EX && g.res[i] ? g.res[i] + (r - b0) : nullptr;
         ldd  = g.ldd[i];
     };
 
@@ -123,7 +125,7 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
 
     const float * xq = x;
     int64_t ldq = ldx;
-    if (g.norm_w) {                                       // the f32 rows sit behind the quantized fields (launcher sizes LDS for it)
+    if (EX && g.norm_w) {                                 // the f32 rows sit behind the quantized fields (launcher sizes LDS for it)
         __shared__ float red[16];
         float * xs = reinterpret_cast<float *>(smem + matvec_lds_bytes<T, NTOK>(K));
         stage_rms_norm<NTOK>(x, ldx, K, g.norm_w, g.norm_eps, xs, red, tid, blockDim.x);
@@ -154,7 +156,7 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
             const float t = wave_sum(acc[n]);
             if (lane == n) out = t;
         }
-        if (lane < NTOK) drow[(int64_t) lane * ldd] = rrow ? out + rrow[(int64_t) lane * ldd] : out;
+        if (lane < NTOK) drow[(int64_t) lane * ldd] = EX && rrow ? out + rrow[(int64_t) lane * ldd] : out;
         if (row + W < total_rows) locate(row + W, wrow, drow, rrow, ldd);
     }
 }
@@ -168,7 +170,7 @@ __host__ __device__ inline size_t kmix_lds_bytes(int ntok, int K) {
     return ((size_t) ntok * K + (size_t) ntok * (K / 256) * 4 + (size_t) ntok * (K / 16) * 2 + 15) & ~(size_t) 15;
 }
 
-template <int NTOK>
+template <int NTOK, bool EX>
 __global__ void __launch_bounds__(1024)
 matvec_kmix_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t ldx, const int K, const int act_mode) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -185,7 +187,7 @@ matvec_kmix_kernel(const MatvecGroup g, const float * __restrict__ x, const int6
 
     const float * xq = x;
     int64_t ldq = ldx;
-    if (g.norm_w) {
+    if (EX && g.norm_w) {
         __shared__ float red[16];
         float * xs = reinterpret_cast<float *>(smem + kmix_lds_bytes(NTOK, K));
         stage_rms_norm<NTOK>(x, ldx, K, g.norm_w, g.norm_eps, xs, red, tid, blockDim.x);
@@ -202,7 +204,7 @@ matvec_kmix_kernel(const MatvecGroup g, const float * __restrict__ x, const int6
             if (k < g.n - 1 && row >= g.row_end[k]) { i = k + 1; b0 = g.row_end[k]; }
         const uint8_t * wrow = g.w[i] + (int64_t) (row - b0) * g.row_bytes[i];
         float * drow = g.dst[i] + (row - b0);
-        const float * rrow = g.res[i] ? g.res[i] + (row - b0) : nullptr;
+        const float * rrow = EX && g.res[i] ? g.res[i] + (row - b0) : nullptr;
         const int64_t ldd = g.ldd[i];
         const int type = __builtin_amdgcn_readfirstlane(g.type[i]);
         float acc[NTOK];
@@ -233,7 +235,7 @@ matvec_kmix_kernel(const MatvecGroup g, const float * __restrict__ x, const int6
             const float t = wave_sum(acc[n]);
             if (lane == n) out = t;
         }
-        if (lane < NTOK) drow[(int64_t) lane * ldd] = rrow ? out + rrow[(int64_t) lane * ldd] : out;
+        if (lane < NTOK) drow[(int64_t) lane * ldd] = EX && rrow ? out + rrow[(int64_t) lane * ldd] : out;
     }
 }
 
