@@ -1118,6 +1118,13 @@ void dev_event_synchronize(ggml_backend_dev_t dev, ggml_backend_event_t event) {
 }
 
 bool dev_supports_op(ggml_backend_dev_t, const struct ggml_tensor * op) {
+    // a row-split tensor has no address of its own (split_buffer_get_base): only the quantized MUL_MAT knows how to read one, as
+    // src0.  Answering "no" here is also what keeps llama.cpp from placing norm weights in the split buffer type
+    // (weight_buft_supported, src/llama-model.cpp:123-242; ggml-cuda.cu:2972-2982 has the same gate).
+    for (int i = 0; i < GGML_MAX_SRC; ++i) {
+        const ggml_tensor * s = op->src[i];
+        if (s && s->buffer && buft_is_split(s->buffer->buft) && !(op->op == GGML_OP_MUL_MAT && i == 0 && type_supported(s->type))) return false;
+    }
     switch (op->op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
             return true;

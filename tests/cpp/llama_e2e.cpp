@@ -3,10 +3,10 @@
 // GGML_BACKEND_PATH and runs llama-bench's protocol on it.  Public llama.h / ggml.h / gguf.h API only.
 //
 //   llama-e2e write   --config NAME --gguf PATH              write the synthetic GGUF (SURVEY §8d "model level" recipe)
-//   llama-e2e bench   --gguf PATH [--ngl N] [-p 512] [-n 128] [-r 3] [-t T]
+//   llama-e2e bench   --gguf PATH [--ngl N] [-p 512] [-n 128] [-r 3] [-t T] [-sm none|layer|row]
 //                         llama-bench's pp / tg test (examples/llama-bench/llama-bench.cpp:1428-1467 test_prompt / test_gen,
 //                         :1605-1642 warm-up + reps): one JSON line with tok/s
-//   llama-e2e compare --gguf PATH [-p 64] [-n 8] [-t T]      same tokens through the CPU backend (ngl 0) and the offloaded
+//   llama-e2e compare --gguf PATH [-p 64] [-n 8] [-t T] [-sm ...]   same tokens through the CPU backend (ngl 0) and the offloaded
 //                         model (ngl 99): NMSE of the logits of the last prompt token and of every generated step
 //
 // llama-bench itself is not built (it needs cmake-generated build-info.cpp); this file is ours and only restates its
@@ -180,9 +180,10 @@ struct Session {
     llama_model *   model = nullptr;
     llama_context * ctx = nullptr;
     int             n_vocab = 0;
-    bool open(const char * gguf, int ngl, int n_ctx, int n_batch, int threads) {
+    bool open(const char * gguf, int ngl, int n_ctx, int n_batch, int threads, int split_mode = -1) {
         llama_model_params mp = llama_model_default_params();
         mp.n_gpu_layers = ngl;
+        if (split_mode >= 0) mp.split_mode = (llama_split_mode) split_mode;      // 1 = layers over the devices, 2 = rows (llama-bench -sm)
         model = llama_model_load_from_file(gguf, mp);
         if (!model) return false;
         llama_context_params cp = llama_context_default_params();
@@ -259,8 +260,10 @@ int main(int argc, char ** argv) {
     if (mode == "bench") {
         const int ngl = atoi(arg(argc, argv, "--ngl", "99")), n_prompt = atoi(arg(argc, argv, "-p", "512")), n_gen = atoi(arg(argc, argv, "-n", "128")),
                   reps = atoi(arg(argc, argv, "-r", "3"));
+        const char * sm = arg(argc, argv, "-sm", "");
+        const int split_mode = !strcmp(sm, "row") ? 2 : !strcmp(sm, "layer") ? 1 : !strcmp(sm, "none") ? 0 : -1;
         Session s;
-        if (!s.open(gguf, ngl, n_prompt + n_gen, std::max(n_prompt, 1), threads)) { fprintf(stderr, "load failed\n"); return 1; }
+        if (!s.open(gguf, ngl, n_prompt + n_gen, std::max(n_prompt, 1), threads, split_mode)) { fprintf(stderr, "load failed\n"); return 1; }
         std::srand(1234);
         if (n_prompt > 0 && test_prompt(s, n_prompt, n_prompt)) return 1;          // warm-up (:1619-1631)
         if (n_gen > 0 && test_gen(s, 1)) return 1;
@@ -288,13 +291,15 @@ int main(int argc, char ** argv) {
     }
     if (mode == "compare") {
         const int n_prompt = atoi(arg(argc, argv, "-p", "64")), n_gen = atoi(arg(argc, argv, "-n", "8"));
+        const char * sm = arg(argc, argv, "-sm", "");
+        const int split_mode = !strcmp(sm, "row") ? 2 : !strcmp(sm, "layer") ? 1 : !strcmp(sm, "none") ? 0 : -1;
         std::vector<std::vector<float>> logits[2];
         std::vector<llama_token> prompt(n_prompt), gen(n_gen);
         std::srand(4321);
         int n_vocab = 0;
         for (int pass = 0; pass < 2; ++pass) {
             Session s;
-            if (!s.open(gguf, pass == 0 ? 0 : 99, n_prompt + n_gen, n_prompt, threads)) { fprintf(stderr, "load failed\n"); return 1; }
+            if (!s.open(gguf, pass == 0 ? 0 : 99, n_prompt + n_gen, n_prompt, threads, pass == 0 ? -1 : split_mode)) { fprintf(stderr, "load failed\n"); return 1; }
             n_vocab = s.n_vocab;
             if (pass == 0) {
                 for (auto & t : prompt) t = std::rand() % n_vocab;

@@ -56,3 +56,14 @@ def test_llama_bench_protocol_runs(gguf):
     r = run("bench", "--gguf", gguf, "-p", "128", "-n", "16", "-r", "1", "-t", "8")
     print(r)
     assert r["pp_tok_s"] > 0 and r["tg_tok_s"] > 0
+
+
+@pytest.mark.parametrize("sm,vd", [("layer", "2"), ("row", "2"), ("row", "3")])
+def test_split_modes_over_logical_devices(gguf, sm, vd):
+    """llama.cpp's -sm layer / -sm row through the unmodified loader and scheduler, over several logical devices on the one GPU
+    (GGML_MI355X_VIRTUAL_DEVICES): layers on different devices exchange activations with cpy_tensor_async + events, row split
+    puts every matmul weight in the split buffer type (and nothing else: supports_op refuses other ops on split operands)."""
+    r = run("compare", "--gguf", gguf, "-p", "40", "-n", "4", "-t", "8", "-sm", sm, env={"GGML_MI355X_VIRTUAL_DEVICES": vd})
+    print(r)
+    assert f"MI355X{int(vd) - 1}" in r["devices"]
+    assert r["worst_nmse"] < 5e-3, r
