@@ -43,6 +43,7 @@ static const Config CONFIGS[] = {
     { "llama2-7b-q4_0",    32, 4096, 11008, 32, 32,  32000, 10000.0f, "q4_0",   0, 0 },
     { "llama3-8b-q4_k_m",  32, 4096, 14336, 32, 8,  128256, 500000.0f, "q4_k_m", 0, 0 },
     { "synth-7b-q4_k",     32, 4096, 11008, 32, 32,  32000, 10000.0f, "q4_k",   0, 0 },
+    { "llama3-70b-q4_k_m", 80, 8192, 28672, 64, 8,  128256, 500000.0f, "q4_k_m", 0, 0 },
     { "mixtral-8x7b-q4_k_m", 32, 4096, 14336, 32, 8, 32000, 1000000.0f, "q4_k_m", 8, 2 },
 };
 
