@@ -28,7 +28,7 @@ OPS_EXPORTS = [
 
 
 class QmmMvExtra(C.Structure):
-    _fields_ = [("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("residual", C.c_void_p * 4)]
+    _fields_ = [("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("residual", C.c_void_p * 4), ("swiglu", C.c_int)]
 
 
 class QmmTensor(C.Structure):
@@ -196,7 +196,7 @@ class Qmm:
         self._chk(self.lib.qmm_mul_mat_group(self.ctx, arr, len(weights), k, x.data_ptr(), x.shape[0], x.stride(0), self._stream()))
         return outs
 
-    def mul_mat_group_ex(self, weights, k, x, outs, norm_w=None, eps=0.0, residuals=None):
+    def mul_mat_group_ex(self, weights, k, x, outs, norm_w=None, eps=0.0, residuals=None, swiglu=0):
         """qmm_mul_mat_group_ex: x -> rms_norm(x, eps) * norm_w while staging (optional), outs[i] = W_i x + residuals[i] (optional)"""
         arr = (QmmWeight * len(weights))()
         for i, ((t, w), o) in enumerate(zip(weights, outs)):
@@ -204,6 +204,7 @@ class Qmm:
         ex = QmmMvExtra()
         ex.norm_w = norm_w.data_ptr() if norm_w is not None else None
         ex.norm_eps = eps
+        ex.swiglu = swiglu
         for i in range(4):
             r = residuals[i] if residuals is not None and i < len(residuals) else None
             ex.residual[i] = r.data_ptr() if r is not None else None

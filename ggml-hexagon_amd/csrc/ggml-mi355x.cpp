@@ -486,7 +486,7 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
         // graph order they are not neighbours (q, rope(q), k, rope(k), v; gate, silu, up), so the scan looks past other
         // nodes and hoists a later MUL_MAT when that is safe (can_hoist).
         qmm_weight ws[4];
-        int n = 0;
+        int n = 0, member[4] = { 0, 0, 0, 0 };                                 // node index (relative) of every matrix of the group
         ws[n++] = qmm_weight{ a->data, (int64_t) a->nb[1], a->ne[1], (float *) dst->data, (int64_t) (dst->nb[1] / sizeof(float)), (int) a->type };
         std::vector<const ggml_tensor *> & skipped = ctx->skipped;
         skipped.clear();
@@ -499,6 +499,7 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
                 float * out = (float *) d->data;
                 if (!can_hoist(d, skipped)) out = (float *) hoist_elsewhere(ctx, d);   // its block is still in use here: compute into scratch
                 if (out) {
+                    member[n] = i;
                     ws[n++] = qmm_weight{ w->data, (int64_t) w->nb[1], w->ne[1], out, (int64_t) (d->nb[1] / sizeof(float)), (int) w->type };
                     done[i] = 1;
                     continue;
@@ -528,6 +529,38 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
                 memcpy(tmp.op_params, pn.rn->op_params, sizeof(tmp.op_params));
                 const enum ggml_status s = compute_glue(ctx, &tmp, QMM_OP_RMS_NORM_MUL, pn.rn->src[0], pn.w, nullptr);
                 if (s != GGML_STATUS_SUCCESS) return s;
+            }
+        }
+        // (c) ffn_gate + ffn_up of a few-token batch whose only readers are silu(gate) and the MUL of the two (build_ffn's SwiGLU):
+        //     the kernel pairs the rows and writes the product; neither projection is stored
+        if (n == 2 && N <= QMM_MATVEC_MAX_N && ws[0].type == ws[1].type && ws[0].M == ws[1].M && !GGML_MI355X_FUSE_OFF()) {
+            auto uses = [&](const ggml_tensor * t) {
+                auto it = std::lower_bound(ctx->readers.begin(), ctx->readers.end(), t,
+                                           [](const mi355x_backend_ctx::reader_info & r, const ggml_tensor * y) { return r.t < y; });
+                return it != ctx->readers.end() && it->t == t ? it->uses : -1;
+            };
+            const ggml_tensor * t0 = nodes[0], * t1 = nodes[member[1]];
+            int js = -1, jm = -1;
+            for (int j = 1; j < n_nodes && j <= 2 * LOOKAHEAD && jm < 0; ++j) {
+                const ggml_tensor * t = nodes[j];
+                if (done[j] || is_noop(t)) continue;
+                if (js < 0) {
+                    if (t->op == GGML_OP_UNARY && ggml_get_unary_op(t) == GGML_UNARY_OP_SILU && (t->src[0] == t0 || t->src[0] == t1)) js = j;
+                    else break;
+                } else {
+                    const ggml_tensor * other = nodes[js]->src[0] == t0 ? t1 : t0;
+                    if (t->op == GGML_OP_MUL && ((t->src[0] == nodes[js] && t->src[1] == other) || (t->src[1] == nodes[js] && t->src[0] == other))) jm = j;
+                    else break;
+                }
+            }
+            if (jm >= 0 && uses(t0) == 1 && uses(t1) == 1 && uses(nodes[js]) == 1 && ggml_are_same_shape(nodes[jm], t0) && nodes[jm]->nb[0] == 4 &&
+                !(nodes[jm]->flags & GGML_TENSOR_FLAG_OUTPUT) && !(t0->flags & GGML_TENSOR_FLAG_OUTPUT) && !(t1->flags & GGML_TENSOR_FLAG_OUTPUT) &&
+                (size_t) N * K * 5 / 4 + (ex.norm_w ? (size_t) N * K * 4 : 0) + 4096 <= 150 * 1024) {
+                ex.swiglu = nodes[js]->src[0] == t0 ? 1 : 2;
+                ws[0].dst = (float *) nodes[jm]->data;
+                ws[0].ldd = (int64_t) (nodes[jm]->nb[1] / sizeof(float));
+                done[js] = done[jm] = 1;
+                use_ex = true;
             }
         }
         // (b) a lone MUL_MAT whose only reader is the residual ADD right behind it (wo, ffn_down): dst = W x + residual, written

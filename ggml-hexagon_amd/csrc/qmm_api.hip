@@ -34,7 +34,7 @@ static int launch_dequant(hipStream_t st, const void * w, int64_t rb, int64_t ro
 }
 
 static bool group_has_extras(const MatvecGroup & g) {
-    bool ex = g.norm_w != nullptr;
+    bool ex = g.norm_w != nullptr || g.swiglu != 0;
     for (int i = 0; i < g.n; ++i) ex = ex || g.res[i] != nullptr;
     return ex;
 }
@@ -45,7 +45,7 @@ static int launch_matvec_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, c
     if (lds > 160 * 1024) return fail(QMM_EUNSUPPORTED, "matvec: %d tokens x K=%d needs %zu B of LDS", NTOK, K, lds);
     auto kern = group_has_extras(g) ? matvec_kernel<T, NTOK, true> : matvec_kernel<T, NTOK, false>;
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    const int total = g.row_end[g.n - 1];
+    const int total = g.swiglu ? g.row_end[0] : g.row_end[g.n - 1];
     // one block per CU (the activation vector is quantized once per CU); 16 waves per block unless there are
     // fewer rows than that per CU.  Every wave gets a contiguous chunk of rows (+-1 row balance).
     int nw = (total + c->cus - 1) / c->cus;
@@ -395,12 +395,18 @@ static int mul_mat_group_impl(qmm_ctx * c, const qmm_weight * ws, int nw, int64_
         if (N > QMM_MATVEC_MAX_N || nw > MV_MAX_GROUP) return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_group_ex: batches of <= %d tokens, <= %d matrices", QMM_MATVEC_MAX_N, MV_MAX_GROUP);
         if (norm_w && ((uintptr_t) norm_w % 16 || ex->norm_eps < 0.0f)) return fail(QMM_EINVAL, "qmm_mul_mat_group_ex: norm weight must be 16-byte aligned, eps >= 0");
         if (norm_w && (size_t) N * K * 4 + (size_t) N * K * 11 / 8 + 4096 > 150 * 1024) return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_group_ex: %lld rows of %lld do not fit LDS with the norm", (long long) N, (long long) K);
+        if (ex->swiglu) {
+            if ((ex->swiglu != 1 && ex->swiglu != 2) || nw != 2 || ws[0].type != ws[1].type || ws[0].M != ws[1].M || ws[0].M <= 0 || ex->residual[0] || ex->residual[1] ||
+                (size_t) N * K * 5 / 4 + (norm_w ? (size_t) N * K * 4 : 0) + 4096 > 150 * 1024)
+                return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_group_ex: swiglu wants two matrices of one type and shape, no residuals, all tokens in one launch");
+        }
     }
     auto extras = [&](MatvecGroup & g, const int * src_index, int64_t n0) {      // residual pointers of the matrices in g, norm parameters
         if (!ex) return;
         for (int k = 0; k < g.n; ++k) g.res[k] = ex->residual[src_index[k]] ? ex->residual[src_index[k]] + n0 * g.ldd[k] : nullptr;
         g.norm_w = norm_w;
         g.norm_eps = ex->norm_eps;
+        g.swiglu = ex->swiglu;
     };
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->s(stream);

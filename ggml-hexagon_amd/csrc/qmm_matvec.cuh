@@ -32,6 +32,7 @@ struct MatvecGroup {
     const float *   res[MV_MAX_GROUP];       // dst = W x + res (same row stride as dst): the residual add behind wo / ffn_down
     const float *   norm_w;                  // x is rms_norm(x) * norm_w, formed while staging (attn_norm / ffn_norm in front of q/k/v, gate/up)
     float           norm_eps;
+    int             swiglu;                  // 1 / 2: two matrices of one type and shape; dst[0] = silu(W_a x) * (W_b x) with a = swiglu - 1
 };
 
 // RMS_NORM * w of the NTOK activation rows into LDS (f32), by every workgroup: K floats per row are one or a few float4 per
@@ -134,6 +135,42 @@ matvec_kernel(const MatvecGroup g, const float * __restrict__ x, const int64_t l
     }
     quantize_rows<ACT, MvUnit<T>::BSG, T>(xq, ldq, NTOK, K, act_mode, aq, ad, ACT == T_Q8_K ? ab : nullptr, tid, blockDim.x);
     __syncthreads();
+
+    if (EX && g.swiglu) {
+        // ffn_gate and ffn_up as row pairs: a wave computes row r of both and writes silu(gate) * up, the SwiGLU of build_ffn
+        // (ggml_silu + ggml_mul, same float operations as unary_kernel): neither product makes a trip through HBM
+        const int ga = g.swiglu - 1, ub = 1 - ga, M = g.row_end[0];
+        for (int row = gw; row < M; row += W) {
+            const uint8_t * wg = g.w[ga] + (int64_t) row * g.row_bytes[ga], * wu = g.w[ub] + (int64_t) row * g.row_bytes[ub];
+            // one row at a time, as in the plain loop (two rows' loads in flight per wave lose on long streams: see above)
+            float tg[NTOK], out = 0.0f;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const uint8_t * wr = pass == 0 ? wg : wu;
+                float acc[NTOK];
+#pragma unroll
+                for (int n = 0; n < NTOK; ++n) acc[n] = 0.0f;
+                for (int it = 0; it < iters; ++it) {
+                    const int u = lane + WAVE * it, uc = min(u, units - 1);
+                    MvUnit<T> un;
+                    un.load(wr, uc);
+#pragma unroll
+                    for (int n = 0; n < NTOK; ++n) {
+                        const float p = un.dot(uc, aq + (size_t) n * K, ad + (size_t) n * (K / act_block<T>()), ab + (size_t) n * (K / MvUnit<T>::BSG));
+                        acc[n] += u < units ? p : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NTOK; ++n) {
+                    const float t = wave_sum(acc[n]);
+                    if (pass == 0) tg[n] = t;
+                    else if (lane == n) out = tg[n] / (1.0f + expf(-tg[n])) * t;
+                }
+            }
+            if (lane < NTOK) g.dst[0][row + (int64_t) lane * g.ldd[0]] = out;
+        }
+        return;
+    }
 
     for (int row = gw; row < total_rows; row += W) {
         float acc[NTOK];

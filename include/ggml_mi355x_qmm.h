@@ -149,11 +149,15 @@ QMM_API int qmm_mul_mat_group(qmm_ctx * ctx, const qmm_weight * ws, int n_weight
  * launch (both optional):
  *   norm_w      x is rms_norm(x, norm_eps) * norm_w (one f32 row of K, 16-byte aligned), formed while the kernel stages its
  *               activations: attn_norm in front of wq/wk/wv, ffn_norm in front of ffn_gate/ffn_up (llama.cpp build_norm);
- *   residual[i] dst_i = W_i x + residual[i] (rows ldd_i apart, may be dst_i itself): the residual add behind wo / ffn_down. */
+ *   residual[i] dst_i = W_i x + residual[i] (rows ldd_i apart, may be dst_i itself): the residual add behind wo / ffn_down;
+ *   swiglu      1 or 2: exactly two matrices of one type and shape, ffn_gate and ffn_up; only ws[0].dst is written:
+ *               dst = silu(W_a x) .* (W_b x) with a = swiglu - 1 (build_ffn's ggml_silu + ggml_mul), each wave computing one
+ *               row of both. */
 typedef struct qmm_mv_extra {
     const float * norm_w;
     float         norm_eps;
     const float * residual[4];
+    int           swiglu;
 } qmm_mv_extra;
 
 QMM_API int qmm_mul_mat_group_ex(qmm_ctx * ctx, const qmm_weight * ws, int n_weights, int64_t K,

@@ -82,6 +82,27 @@ def test_mat_vec_with_norm_and_residual(qmm, oracle, n):
         assert rel_rms(acc[0].cpu().numpy(), oracle.mul_mat(ws_np[0][0], ws_np[0][1], k, x, ACT_REF) + res[0]) < 2e-5
 
 
+@pytest.mark.parametrize("n", [1, 4, 8])
+def test_mat_vec_swiglu_pairs(qmm, oracle, n):
+    """qmm_mul_mat_group_ex with swiglu: ffn_gate and ffn_up as row pairs, dst = silu(Wg x) * (Wu x), either order, with and
+    without the norm in front"""
+    import ggml_hexagon_amd.synth as synth
+    rng = np.random.default_rng(300 + n)
+    for t, k, m in ((Q4_K, 1024, 704), (Q4_0, 512, 130), (Q6_K, 2048, 96)):
+        x = rng.normal(0, 1.0, (n, k)).astype(np.float32)
+        w = rng.normal(1, 0.1, k).astype(np.float32)
+        wg, wu = synth.synth_weights(t, m, k, seed=11, sigma=0.25), synth.synth_weights(t, m, k, seed=12, sigma=0.25)
+        for which, norm in ((1, False), (2, True)):
+            xin = rms_norm(x, w, 1e-5) if norm else x
+            g, u = oracle.mul_mat(t, wg, k, xin, ACT_REF).astype(np.float64), oracle.mul_mat(t, wu, k, xin, ACT_REF).astype(np.float64)
+            want = g / (1.0 + np.exp(-g)) * u
+            ws = [(t, dev(wg)), (t, dev(wu))] if which == 1 else [(t, dev(wu)), (t, dev(wg))]
+            outs = [torch.full((n, m), 7.0, device="cuda"), torch.full((n, m), 7.0, device="cuda")]
+            qmm.mul_mat_group_ex(ws, k, dev(x), outs, norm_w=dev(w) if norm else None, eps=1e-5, swiglu=which)
+            assert rel_rms(outs[0].cpu().numpy(), want) < 1e-4, (TYPE_NAMES[t], n, which)
+            assert torch.all(outs[1] == 7.0)                      # the second destination is not written
+
+
 def test_add_rms_norm_two_results(qmm):
     from ggml_hexagon_amd import capi
     rng = np.random.default_rng(5)
