@@ -824,6 +824,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
     rd.clear();
     ctx->redirects.clear();
     ctx->hoist_used = 0;
+    ctx->pending_norm = {};
     if (!GGML_MI355X_FUSE_OFF()) {
         for (int i = 0; i + 1 < cgraph->n_nodes; ++i) {
             const ggml_tensor * n0 = cgraph->nodes[i];

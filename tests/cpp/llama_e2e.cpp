@@ -6,7 +6,7 @@
 //   llama-e2e bench   --gguf PATH [--ngl N] [-p 512] [-n 128] [-r 3] [-t T] [-sm none|layer|row]
 //                         llama-bench's pp / tg test (examples/llama-bench/llama-bench.cpp:1428-1467 test_prompt / test_gen,
 //                         :1605-1642 warm-up + reps): one JSON line with tok/s
-//   llama-e2e compare --gguf PATH [-p 64] [-n 8] [-t T] [-sm ...]   same tokens through the CPU backend (ngl 0) and the offloaded
+//   llama-e2e compare --gguf PATH [-p 64] [-n 8] [-t T] [-sm ...] [--ngl N]   same tokens through the CPU backend (ngl 0) and the offloaded
 //                         model (ngl 99): NMSE of the logits of the last prompt token and of every generated step
 //
 // llama-bench itself is not built (it needs cmake-generated build-info.cpp); this file is ours and only restates its
@@ -294,13 +294,14 @@ int main(int argc, char ** argv) {
         const int n_prompt = atoi(arg(argc, argv, "-p", "64")), n_gen = atoi(arg(argc, argv, "-n", "8"));
         const char * sm = arg(argc, argv, "-sm", "");
         const int split_mode = !strcmp(sm, "row") ? 2 : !strcmp(sm, "layer") ? 1 : !strcmp(sm, "none") ? 0 : -1;
+        const int ngl = atoi(arg(argc, argv, "--ngl", "99"));                // layers offloaded in the second pass (partial offload: < n_layer)
         std::vector<std::vector<float>> logits[2];
         std::vector<llama_token> prompt(n_prompt), gen(n_gen);
         std::srand(4321);
         int n_vocab = 0;
         for (int pass = 0; pass < 2; ++pass) {
             Session s;
-            if (!s.open(gguf, pass == 0 ? 0 : 99, n_prompt + n_gen, n_prompt, threads, pass == 0 ? -1 : split_mode)) { fprintf(stderr, "load failed\n"); return 1; }
+            if (!s.open(gguf, pass == 0 ? 0 : ngl, n_prompt + n_gen, n_prompt, threads, pass == 0 ? -1 : split_mode)) { fprintf(stderr, "load failed\n"); return 1; }
             n_vocab = s.n_vocab;
             if (pass == 0) {
                 for (auto & t : prompt) t = std::rand() % n_vocab;

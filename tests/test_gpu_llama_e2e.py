@@ -67,3 +67,12 @@ def test_split_modes_over_logical_devices(gguf, sm, vd):
     print(r)
     assert f"MI355X{int(vd) - 1}" in r["devices"]
     assert r["worst_nmse"] < 5e-3, r
+
+
+@pytest.mark.parametrize("ngl", ["1", "3"])
+def test_partial_offload(gguf, ngl):
+    """-ngl below the layer count: offloaded and CPU layers alternate in one graph, so the residual stream crosses the split
+    boundary: every fused launch must still leave what the next split reads (the ADD results) in memory"""
+    r = run("compare", "--gguf", gguf, "-p", "40", "-n", "4", "-t", "8", "--ngl", ngl)
+    print(r)
+    assert r["worst_nmse"] < 5e-3, r
