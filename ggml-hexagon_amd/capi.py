@@ -18,7 +18,7 @@ EXPORTS = [
     "qmm_memcpy_d2h", "qmm_memcpy_d2d", "qmm_memset", "qmm_synchronize", "qmm_memcpy2d_d2d", "qmm_event_create",
     "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_memcpy_h2d_async",
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_dequantize",
-    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
+    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_swiglu_in", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
 ]
 # include/ggml_mi355x_ops.h: the glue ops of a transformer layer
 OPS_EXPORTS = [
@@ -104,6 +104,7 @@ def load_library() -> C.CDLL:
     lib.qmm_quantize_act.argtypes = [v, i32, v, i64, i64, i64, v, v, v, v]
     lib.qmm_mul_mat.argtypes = [v, i32, v, i64, i64, i64, v, i64, i64, v, i64, v]
     lib.qmm_mul_mat_group.argtypes = [v, C.POINTER(QmmWeight), i32, i64, v, i64, i64, v]
+    lib.qmm_mul_mat_swiglu_in.argtypes = [v, i32, v, i64, i64, i64, v, i64, v, i64, i64, v, i64, v]
     lib.qmm_mul_mat_group_ex.argtypes = [v, C.POINTER(QmmWeight), i32, i64, v, i64, i64, C.POINTER(QmmMvExtra), v]
     P = C.POINTER(QmmTensor)
     lib.qmm_op_supported.argtypes = [i32, P, P, P, P]

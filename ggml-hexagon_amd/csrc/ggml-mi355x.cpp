@@ -69,6 +69,8 @@ struct mi355x_backend_ctx {
     std::vector<char>                done;
     std::vector<const ggml_tensor *> deferred;       // per node: the SILU whose result this MUL consumes in the same launch
     // RMS_NORM -> MUL(w) held back for the MUL_MATs that read it (few-token batches): they form the normed row while staging
+    struct swiglu_src { const float * gate = nullptr; const float * up = nullptr; int64_t ld_gate = 0, ld_up = 0; };
+    std::vector<swiglu_src>          swiglu_in;      // per node: this ffn_down forms silu(gate) * up in its activation prep (prompt batches)
     struct norm_req { const ggml_tensor * rn = nullptr, * mul = nullptr, * w = nullptr; int readers = 0; };
     norm_req                         pending_norm;
 };
@@ -864,6 +866,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
     done.assign(n_nodes, 0);
     std::vector<const ggml_tensor *> & deferred = ctx->deferred;
     deferred.assign(n_nodes, nullptr);
+    ctx->swiglu_in.assign(n_nodes, {});
     for (int i = 0; i < n_nodes; ++i) {
         struct ggml_tensor * node = cgraph->nodes[i];
         if (done[i] || is_noop(node)) continue;                                      // ggml-hexagon.cpp:5561-5566
@@ -876,7 +879,23 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
             if (deferred[i]) {
                 // MUL whose operand is a SILU that was held back: silu(gate) * up in one pass
                 const ggml_tensor * silu = deferred[i];
-                st = compute_glue(ctx, node, QMM_OP_SILU_MUL, silu->src[0], node->src[0] == silu ? node->src[1] : node->src[0], nullptr);
+                const ggml_tensor * gate = silu->src[0], * up = node->src[0] == silu ? node->src[1] : node->src[0];
+                // prompt batch, and the product feeds exactly one quantized MUL_MAT right behind it (ffn_down): that MUL_MAT's
+                // activation prep reads gate and up itself; no launch and no round trip for the product
+                int j = i + 1;
+                while (j < n_nodes && (done[j] || is_noop(cgraph->nodes[j]))) ++j;
+                if (j < n_nodes && node->ne[1] > QMM_MATVEC_MAX_N && node->ne[2] == 1 && node->ne[3] == 1 && single_use(node) &&
+                    !(node->flags & GGML_TENSOR_FLAG_OUTPUT) && !getenv("GGML_MI355X_PREC")) {
+                    const ggml_tensor * mm = cgraph->nodes[j], * w = mm->src[0];
+                    const qmm_tensor qg = to_qt(gate, ctx), qu = to_qt(up, ctx);      // resolved now: a redirect may expire before node j
+                    if (mm->op == GGML_OP_MUL_MAT && !glue_op(mm) && mm->src[1] == node && supports_mul_mat(mm) && is_ours(w) && !is_split(w) &&
+                        w->ne[2] == 1 && w->ne[3] == 1 && gate->nb[0] == 4 && up->nb[0] == 4 && gate->nb[1] % 16 == 0 && up->nb[1] % 16 == 0 &&
+                        (uintptr_t) qg.data % 16 == 0 && (uintptr_t) qu.data % 16 == 0) {
+                        ctx->swiglu_in[j] = { (const float *) qg.data, (const float *) qu.data, (int64_t) (gate->nb[1] / 4), (int64_t) (up->nb[1] / 4) };
+                        continue;
+                    }
+                }
+                st = compute_glue(ctx, node, QMM_OP_SILU_MUL, gate, up, nullptr);
                 if (st != GGML_STATUS_SUCCESS) return st;
                 continue;
             }
@@ -1071,6 +1090,15 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                 st = compute_glue(ctx, node, gop, node->src[0], nullptr, nullptr);
             } else {
                 st = compute_glue(ctx, node, gop, node->src[0], node->src[1], node->src[2]);
+            }
+        } else if (node->op == GGML_OP_MUL_MAT && ctx->swiglu_in[i].gate) {
+            const ggml_tensor * w = node->src[0];
+            const auto & sg = ctx->swiglu_in[i];
+            st = GGML_STATUS_SUCCESS;
+            if (qmm_mul_mat_swiglu_in(ctx->dev->qmm, w->type, w->data, w->nb[1], w->ne[0], w->ne[1], sg.gate, sg.ld_gate, sg.up, sg.ld_up,
+                                      node->src[1]->ne[1], (float *) node->data, node->nb[1] / sizeof(float), qmm_stream(ctx->dev->qmm))) {
+                GGML_LOG_ERROR("MI355X MUL_MAT(%s) with SwiGLU input: %s\n", node->name, qmm_last_error());
+                st = GGML_STATUS_FAILED;
             }
         } else if (node->op == GGML_OP_MUL_MAT) {
             st = compute_mul_mat(ctx, cgraph->nodes + i, n_nodes - i, done.data() + i);                      // may hoist later MUL_MATs

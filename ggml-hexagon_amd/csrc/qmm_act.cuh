@@ -85,12 +85,28 @@ __device__ __forceinline__ void q8_K_block(const float4 v, int lane, uint32_t & 
     d_out = __fdiv_rn(1.0f, iscale);
 }
 
+// X2 instantiations: the activations are SwiGLU of two rows, silu(x) * x2 (llama.cpp build_ffn, LLM_FFN_SILU + LLM_FFN_PAR: the
+// input of ffn_down), formed while staging; same float operations as the stand-alone SILU and MUL kernels.
+template <bool X2>
+__device__ __forceinline__ float4 act_fetch(const float * __restrict__ p, const float * __restrict__ p2) {
+    float4 v = *reinterpret_cast<const float4 *>(p);
+    if (X2) {
+        const float4 u = *reinterpret_cast<const float4 *>(p2);
+        v.x = v.x / (1.0f + expf(-v.x)) * u.x;
+        v.y = v.y / (1.0f + expf(-v.y)) * u.y;
+        v.z = v.z / (1.0f + expf(-v.z)) * u.z;
+        v.w = v.w / (1.0f + expf(-v.w)) * u.w;
+    }
+    return v;
+}
+
 // Quantize `rows` activation rows of length K into (q, d, bsum).  All threads of the block take part;
 // the caller synchronizes afterwards.  ACT = T_Q8_0 or T_Q8_K.  Row r of x starts at x + r*ldx;
 // outputs for row r at q + r*K, d + r*(K/blk), bsum + r*(K/16).
-template <int ACT, int BSG = 16, int SWZ = 0>
+template <int ACT, int BSG = 16, int SWZ = 0, bool X2 = false>
 __device__ __forceinline__ void quantize_rows(const float * __restrict__ x, int64_t ldx, int rows, int K, int act_mode,
-                                              int8_t * q, float * d, int16_t * bsum, int tid, int nthreads) {
+                                              int8_t * q, float * d, int16_t * bsum, int tid, int nthreads,
+                                              const float * __restrict__ x2 = nullptr, int64_t ldx2 = 0) {
     if (ACT == T_Q8_0) {
         const int per_row = K / 4;                               // float4 slots per row
         const int total = rows * per_row;                        // multiple of 8
@@ -98,7 +114,7 @@ __device__ __forceinline__ void quantize_rows(const float * __restrict__ x, int6
             const bool live = i < total;                         // keep the 8-lane groups converged
             const int r = live ? i / per_row : 0, c = live ? i % per_row : 0;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live) v = *reinterpret_cast<const float4 *>(x + (int64_t) r * ldx + 4 * c);
+            if (live) v = act_fetch<X2>(x + (int64_t) r * ldx + 4 * c, X2 ? x2 + (int64_t) r * ldx2 + 4 * c : nullptr);
             uint32_t p; float dd;
             q8_0_block(v, act_mode, p, dd);
             if (live) {
@@ -119,18 +135,22 @@ __device__ __forceinline__ void quantize_rows(const float * __restrict__ x, int6
         };
         for (int r = 0; r < rows; ++r) {                         // rows is a small compile-time constant at the hot call sites
             const float * xr = x + (int64_t) r * ldx + 4 * lane;
+            const float * x2r = X2 ? x2 + (int64_t) r * ldx2 + 4 * lane : nullptr;
             int8_t *  qr = q + (size_t) r * K;
             float *   dr = d + (size_t) r * nb;
             int16_t * br = bsum ? bsum + (size_t) r * (K / BSG) : nullptr;
             if (nb <= nwaves) {                                  // at most one block per wave (K = 4096 with 16 waves)
-                if (wave < nb) emit(*reinterpret_cast<const float4 *>(xr + wave * 256), qr, dr, br, wave);
+                if (wave < nb) emit(act_fetch<X2>(xr + wave * 256, X2 ? x2r + wave * 256 : nullptr), qr, dr, br, wave);
                 continue;
             }
             // long rows (K = 14336: 56 blocks over 16 waves): four blocks' loads in flight per wave, unconditional + clamped
             for (int b0 = wave; b0 < nb; b0 += 4 * nwaves) {
                 float4 v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4 *>(xr + min(b0 + j * nwaves, nb - 1) * 256);
+                for (int j = 0; j < 4; ++j) {
+                    const int off = min(b0 + j * nwaves, nb - 1) * 256;
+                    v[j] = act_fetch<X2>(xr + off, X2 ? x2r + off : nullptr);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (b0 + j * nwaves < nb) emit(v[j], qr, dr, br, b0 + j * nwaves);     // wave-uniform, no load inside

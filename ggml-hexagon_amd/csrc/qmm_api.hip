@@ -493,6 +493,24 @@ static int mul_mat_group_impl(qmm_ctx * c, const qmm_weight * ws, int nw, int64_
     return QMM_OK;
 }
 
+// dst = W * (silu(gate) .* up) for a prompt batch: ffn_down with the SwiGLU product formed by the activation prep of the MFMA path
+// (one workgroup per token row reads both rows), so the product never exists in HBM.  Few-token batches fold it on the
+// producer side instead (qmm_mv_extra.swiglu).
+int qmm_mul_mat_swiglu_in(qmm_ctx * c, int type, const void * w, int64_t w_row_bytes, int64_t K, int64_t M, const float * gate, int64_t ld_gate,
+                          const float * up, int64_t ld_up, int64_t N, float * dst, int64_t ldd, void * stream) {
+    if (!c) return fail(QMM_EINVAL, "qmm_mul_mat_swiglu_in: NULL context");
+    if (N <= QMM_MATVEC_MAX_N) return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_swiglu_in: batches above %d tokens (below: qmm_mv_extra.swiglu)", QMM_MATVEC_MAX_N);
+    if (c->prec != QMM_PREC_F16_Q8) return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_swiglu_in: only in the default prefill mode");
+    if ((uintptr_t) up % 16 || ld_up % 4 || ld_up < K) return fail(QMM_EINVAL, "qmm_mul_mat_swiglu_in: up must be 16-byte aligned, ld_up %% 4 == 0, ld_up >= K");
+    const qmm_weight ws = { w, w_row_bytes, M, dst, ldd, type };
+    c->prep_x2 = up;
+    c->prep_ldx2 = ld_up;
+    const int rc = mul_mat_group_impl(c, &ws, 1, K, gate, N, ld_gate, stream, nullptr);
+    c->prep_x2 = nullptr;
+    c->prep_ldx2 = 0;
+    return rc;
+}
+
 int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, const float * x, int64_t N, int64_t ldx, void * stream) {
     return mul_mat_group_impl(c, ws, nw, K, x, N, ldx, stream, nullptr);
 }

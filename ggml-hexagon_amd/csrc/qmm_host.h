@@ -28,6 +28,8 @@ struct qmm_ctx {
     void *      ws = nullptr;
     size_t      ws_bytes = 0;
     int *       flag = nullptr;      // device word set by kernels that meet an expert id out of range
+    const float * prep_x2 = nullptr; // transient: second operand of a SwiGLU input while qmm_mul_mat_swiglu_in runs (prefill prep)
+    int64_t     prep_ldx2 = 0;
     int         splitk = 1;          // split K over workgroups when a MUL_MAT has too few tiles (GGML_MI355X_SPLITK=0: off)
     char        name[128] = {0};
 

@@ -79,7 +79,8 @@ template <int ACT, bool F16Q8, int PERM>
 __global__ void __launch_bounds__(256)
 prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t * __restrict__ gather,
                 const int * __restrict__ n_rows_dev, const int n_rows, const int K, const int Kp, const int act_mode,
-                const int frag_major, uint16_t * __restrict__ xh, float * __restrict__ scale) {
+                const int frag_major, uint16_t * __restrict__ xh, float * __restrict__ scale,
+                const float * __restrict__ x2 = nullptr, const int64_t ldx2 = 0) {      // x2: the row is silu(x) * x2 (qmm_mul_mat_swiglu_in)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int r = blockIdx.x;
     const int tid = threadIdx.x;
@@ -114,7 +115,8 @@ prep_act_kernel(const float * __restrict__ x, const int64_t ldx, const int64_t *
     int8_t * aq = reinterpret_cast<int8_t *>(smem);
     float *  ad = reinterpret_cast<float *>(smem + K);
     float *  red = ad + K / QB;                              // 4 floats for the block max
-    quantize_rows<ACT>(src, 0, 1, K, act_mode, aq, ad, nullptr, tid, 256);
+    if (x2) quantize_rows<ACT, 16, 0, true>(src, 0, 1, K, act_mode, aq, ad, nullptr, tid, 256, x2 + (int64_t) r * ldx2, 0);
+    else    quantize_rows<ACT>(src, 0, 1, K, act_mode, aq, ad, nullptr, tid, 256);
     __syncthreads();
     float mx = 0.0f;
     for (int b = tid; b < K / QB; b += 256) mx = fmaxf(mx, fabsf(ad[b]));
@@ -459,16 +461,18 @@ template <int ACT>
 inline int launch_prep(qmm_ctx * c, hipStream_t st, int type, const float * x, int64_t ldx, const int64_t * gather, const int * n_dev,
                        int n_rows, int n_pad, int K, int Kp, int frag_major, uint16_t * xh, float * scale) {
     const size_t lds = (size_t) K + (size_t) (K / 32) * 4 + 64;
+    const float * x2 = gather ? nullptr : c->prep_x2;                        // set by qmm_mul_mat_swiglu_in around the call
+    if (x2 && c->prec != QMM_PREC_F16_Q8) return fail(QMM_EUNSUPPORTED, "SwiGLU input: only in the default (f16 on Q8 activations) prefill mode");
 #define QMM_PREP(PERMv)                                                                                                            \
     hipLaunchKernelGGL((prep_act_kernel<ACT, true, PERMv>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,     \
-                       c->act_mode, frag_major, xh, scale)
+                       c->act_mode, frag_major, xh, scale, x2, c->prep_ldx2)
     if (c->prec == QMM_PREC_F16_Q8 && (type == T_Q4_K || type == T_Q5_K)) QMM_PREP(2);      // register-B lane orders (qmm_mfma_regb.cuh)
     else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q8_0) QMM_PREP(5);
     else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q6_K) QMM_PREP(3);
     else if (c->prec == QMM_PREC_F16_Q8 && type == T_Q4_0) QMM_PREP(4);
     else if (c->prec == QMM_PREC_F16_Q8)
         hipLaunchKernelGGL((prep_act_kernel<ACT, true, 0>), dim3(n_pad), dim3(256), lds, st, x, ldx, gather, n_dev, n_rows, K, Kp,
-                           c->act_mode, frag_major, xh, scale);
+                           c->act_mode, frag_major, xh, scale, x2, c->prep_ldx2);
     else
         hipLaunchKernelGGL((prep_act_kernel<ACT, false, 0>), dim3(n_pad), dim3(256), 0, st, x, ldx, gather, n_dev, n_rows, K, Kp,
                            c->act_mode, frag_major, xh, scale);

@@ -163,6 +163,12 @@ typedef struct qmm_mv_extra {
 QMM_API int qmm_mul_mat_group_ex(qmm_ctx * ctx, const qmm_weight * ws, int n_weights, int64_t K,
                                  const float * x, int64_t N, int64_t ldx, const qmm_mv_extra * extra, void * stream);
 
+/* dst = W * (silu(gate) .* up) for a prompt batch (N > QMM_MATVEC_MAX_N): ffn_down with build_ffn's SwiGLU product formed by the
+ * activation prep of the MFMA path; gate / up rows are ld_gate / ld_up floats apart.  Default prefill precision only. */
+QMM_API int qmm_mul_mat_swiglu_in(qmm_ctx * ctx, int type, const void * w, int64_t w_row_bytes, int64_t K, int64_t M,
+                                  const float * gate, int64_t ld_gate, const float * up, int64_t ld_up, int64_t N,
+                                  float * dst, int64_t ldd, void * stream);
+
 /* GGML_OP_MUL_MAT_ID.
  *   as   [K, M, n_expert]  experts `expert_bytes` apart
  *   b    f32 [K, ne11, n_tokens]   element (k, i11, t) at b[t*b_nb2/4 + i11*b_nb1/4 + k]   (ne11 = n_used or 1)

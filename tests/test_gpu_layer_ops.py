@@ -103,6 +103,26 @@ def test_mat_vec_swiglu_pairs(qmm, oracle, n):
             assert torch.all(outs[1] == 7.0)                      # the second destination is not written
 
 
+@pytest.mark.parametrize("n", [9, 40, 300])
+def test_prefill_with_swiglu_input(qmm, oracle, n):
+    """qmm_mul_mat_swiglu_in: dst = W (silu(gate) * up) with the product formed by the MFMA path's activation prep; against the
+    oracle fed with the numpy product (prefill bar: rel-L2 <= 1e-3)"""
+    import ggml_hexagon_amd.synth as synth
+    rng = np.random.default_rng(500 + n)
+    for t, k, m in ((Q4_K, 2816, 1024), (Q6_K, 1024, 300), (Q4_0, 512, 128)):
+        gate = rng.normal(0, 1.0, (n, k)).astype(np.float32)
+        up = rng.normal(0, 1.0, (n, k)).astype(np.float32)
+        x = (gate / (1.0 + np.exp(-gate)) * up).astype(np.float32)
+        w = synth.synth_weights(t, m, k, seed=21, sigma=0.25)
+        wd, dg, du = dev(w), dev(gate), dev(up)
+        out = torch.zeros((n, m), device="cuda")
+        qmm._chk(qmm.lib.qmm_mul_mat_swiglu_in(qmm.ctx, t, wd.data_ptr(), wd.stride(0), k, m, dg.data_ptr(), k, du.data_ptr(), k, n,
+                                               out.data_ptr(), m, qmm._stream()))
+        want = oracle.mul_mat(t, w, k, x, ACT_REF).astype(np.float64)
+        got = out.cpu().numpy()
+        assert np.sqrt(np.sum((got - want) ** 2) / np.sum(want ** 2)) < 1e-3, (TYPE_NAMES[t], n)
+
+
 def test_add_rms_norm_two_results(qmm):
     from ggml_hexagon_amd import capi
     rng = np.random.default_rng(5)
