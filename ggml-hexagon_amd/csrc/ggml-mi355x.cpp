@@ -1,14 +1,18 @@
 // ggml-mi355x.cpp — ggml backend plugin for MI355X: reg / device / buffer type / buffer / backend vtables
-// (contract: ggml/src/ggml-backend-impl.h:17-207) over the kernel C-ABI of include/ggml_mi355x_qmm.h.
+// (contract: ggml/src/ggml-backend-impl.h:17-207) over the kernel C-ABI of include/ggml_mi355x_qmm.h (quantized MUL_MAT /
+// MUL_MAT_ID, the hot path) and include/ggml_mi355x_ops.h (the other ops of a transformer layer).
 //
 // Mirrors the structure of the reference's "backend per ggml spec" section
 // (ggml/src/ggml-hexagon/ggml-hexagon.cpp:5417-5427 buffer iface, 5708-5737 buffer type, 5818-5834 device iface,
 // 5555-5574 graph_compute node loop, 5065-5115 supports_op gate, 5941-6007 reg, 6066-6125 init, 6127 DL_IMPL),
-// with three deliberate differences:
+// with four deliberate differences:
 //   * buffers are real HBM (is_host = false): weights are uploaded once by set_tensor and never re-marshalled
 //     (the reference re-maps tensor memory through FastRPC per call, ggml-hexagon.cpp:4975-5060);
 //   * op failures are reported as GGML_STATUS_FAILED (the reference logs and continues, :5053-5056);
-//   * consecutive MUL_MAT nodes that share src1 are issued as one grouped launch when the batch is <= 8.
+//   * graph_compute schedules a split instead of walking it: MUL_MATs that share src1 run as one launch although llama.cpp's
+//     graph order separates them, and chains of nodes (norm -> weight -> projections, projection -> residual add, gate / up ->
+//     SwiGLU, rope -> KV-cache stores, KQ -> soft_max -> KQV -> head merge) run as single launches;
+//   * pinned host buffers, asynchronous copies and events, so llama.cpp's pipelined loader applies.
 // Row split over the devices of this process (llama.cpp -sm row) is the split buffer type at the end of the file.
 //
 // This file includes only ggml headers and the C-ABI; all HIP lives in libggml_mi355x_qmm.so.
@@ -1284,7 +1288,8 @@ ggml_backend_reg_t ggml_backend_mi355x_reg(void) {
             d.buft = ggml_backend_buffer_type{ buft_iface, &g_devices[g_ndev], &d };
             ++g_ndev;
         }
-        GGML_LOG_INFO("MI355X backend: %d device(s); offloads quantized MUL_MAT / MUL_MAT_ID (Q4_0 Q8_0 Q4_K Q5_K Q6_K)\n", g_ndev);
+        GGML_LOG_INFO("MI355X backend: %d device(s); quantized MUL_MAT / MUL_MAT_ID (Q4_0 Q8_0 Q4_K Q5_K Q6_K)%s\n", g_ndev,
+                      GGML_MI355X_GLUE_OFF() ? "" : " and the glue ops of a transformer layer");
     });
     return &reg;
 }
