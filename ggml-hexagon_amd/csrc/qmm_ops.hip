@@ -325,6 +325,27 @@ struct RopeParams {
     int   n_dims, neox;
     float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
 };
+// cos / sin of pair p at position pos (rope_yarn + ggml_rope_cache_init, ggml-cpu.c:8610-8648): theta by the CPU's repeated f32 multiply
+__device__ __forceinline__ void rope_cs(const float pos, const uint32_t p, const RopeParams & rp, const float * __restrict__ ff, float & c, float & s) {
+    float theta = pos;
+    for (uint32_t k = 0; k < p; ++k) theta *= rp.theta_scale;
+    const float theta_extrap = theta / (ff ? ff[p] : 1.0f);
+    const float theta_interp = rp.freq_scale * theta_extrap;
+    float th = theta_interp, mscale = rp.attn_factor;
+    if (rp.ext_factor != 0.0f) {
+        const float yv = ((float) p - rp.corr0) / fmaxf(0.001f, rp.corr1 - rp.corr0);
+        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, yv))) * rp.ext_factor;
+        th = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / rp.freq_scale);
+    }
+    // th can be thousands of radians (position times the first frequencies): ocml's sinf / cosf take their large-argument
+    // path there.  One reduction in double (exact to ~1e-13 rad) and the fast pair on the remainder give the same values
+    // to f32 rounding at a fraction of the instructions.
+    const double td = (double) th;
+    const float r = (float) (td - 6.283185307179586 * rint(td * 0.15915494309189535));
+    c = cosf(r) * mscale;
+    s = sinf(r) * mscale;
+}
 // one pair of one row; TD = float or __half (the K-cache store of build_attn is rope(k) -> f16)
 template <typename TD>
 __device__ __forceinline__ void rope_pair(const char * __restrict__ x, const int32_t * __restrict__ pos, const float * __restrict__ ff,
@@ -341,18 +362,8 @@ __device__ __forceinline__ void rope_pair(const char * __restrict__ x, const int
         py[i0 + 1] = (TD) px[i0 + 1];
         return;
     }
-    float theta = (float) pos[i2];
-    for (uint32_t k = 0; k < p; ++k) theta *= rp.theta_scale;
-    const float theta_extrap = theta / (ff ? ff[p] : 1.0f);
-    const float theta_interp = rp.freq_scale * theta_extrap;
-    float th = theta_interp, mscale = rp.attn_factor;
-    if (rp.ext_factor != 0.0f) {
-        const float yv = ((float) (i0 / 2) - rp.corr0) / fmaxf(0.001f, rp.corr1 - rp.corr0);
-        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, yv))) * rp.ext_factor;
-        th = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
-        mscale *= 1.0f + 0.1f * logf(1.0f / rp.freq_scale);
-    }
-    const float c = cosf(th) * mscale, s = sinf(th) * mscale;
+    float c, s;
+    rope_cs((float) pos[i2], p, rp, ff, c, s);
     const uint32_t ia = rp.neox ? p : i0, ib = rp.neox ? p + rp.n_dims / 2 : i0 + 1;
     const float x0 = px[ia], x1 = px[ib];
     py[ia] = (TD) (x0 * c - x1 * s);
@@ -613,39 +624,101 @@ struct AttnArgs {
 // 16 waves per workgroup and several independent loads in flight per lane: with one (head, token) per workgroup the kernel is
 // bound by load latency, not bandwidth (the first version, 4 waves and one row per lane group at a time, took 22 us at
 // n_kv = 640; the four separate launches it replaces took 16).
-template <int D>
+// FRESH: the batch's own K / V rows are not in the cache yet — the launch also does what precedes the attention in build_attn
+// (src/llama-graph.cpp:1306-1365): rope(q), rope(k) -> K cache, v -> V cache.  q arrives un-roped; every workgroup ropes the N
+// new K rows of its kv head and converts the N new V rows into LDS and takes them from there for cache positions
+// j0 .. j0 + N (no workgroup reads those positions from memory, so the one workgroup per kv head that also stores them races
+// with nobody).  Normal-mode RoPE over the whole head (n_dims == D).
+struct AttnFresh {
+    const char * kraw; const char * vraw; char * kd; char * vd; const int32_t * pos; const float * ff;
+    int64_t kraw_nbh, kraw_nbn, vraw_nbn, kd_nbh, kd_nbn, vd_nbc;
+    RopeParams rp;
+    int32_t N, j0;
+};
+template <int D, bool FRESH>
 __global__ void __launch_bounds__(1024)
-attn_decode_kernel(const AttnArgs g) {
-    extern __shared__ float sc[];                       // n_kv scores, then probabilities
+attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
+    extern __shared__ float sc[];                       // n_kv scores, then probabilities [FRESH: + q row f32, new K rows, new V rows f16]
     __shared__ float red[16];
     const int h = blockIdx.x, n = blockIdx.y, hk = h / g.gqa;
     const int tid = threadIdx.x, l8 = tid & 7, grp = tid >> 3;          // 128 groups of 8 lanes: one K row per group
     constexpr int CH = D / 8;                           // halves of a K row per lane
     constexpr int NV = CH / 8;                          // 16-byte loads per lane and row
-    float qf[CH];
-    {
-        const float * pq = (const float *) (g.q + (int64_t) n * g.q_nb1 + (int64_t) h * g.q_nb2) + l8 * CH;
-#pragma unroll
-        for (int e = 0; e < CH; ++e) qf[e] = (float) (_Float16) pq[e];
-    }
+    float *    qs   = sc + g.n_kv;                      // FRESH only
+    _Float16 * knew = reinterpret_cast<_Float16 *>(qs + D);
+    _Float16 * vnew = knew + (FRESH ? f.N * D : 0);
     const float * pm = (const float *) (g.mask + (int64_t) n * g.m_nb1);
     const char *  pk = g.k + (int64_t) hk * g.k_nb2 + (int64_t) l8 * CH * 2;
-    float mx = -INFINITY;
-    for (int j0 = grp; j0 < g.n_kv; j0 += 256) {        // two rows (j0, j0 + 128) per trip, their loads issued together
-        h16x8 kv[2][NV];
-        float mk[2];
+    // two rows (jt, jt + 128) per trip, their loads issued together and one trip ahead of the arithmetic; the first trip is
+    // requested before anything else, so with FRESH the cache rows are already on their way while q / k / v are prepared
+    auto load_trip = [&](int jt, h16x8 (&kv)[2][NV], float (&mk)[2]) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int j = j0 + r * 128;
-            const int jc = j < g.n_kv ? j : j0;
+            const int j = jt + r * 128, jc = j < g.n_kv ? j : jt;
             const h16x8 * row = (const h16x8 *) (pk + (int64_t) jc * g.k_nb1);
 #pragma unroll
             for (int c = 0; c < NV; ++c) kv[r][c] = row[c];
             mk[r] = pm[jc];
         }
+    };
+    h16x8 kv[2][NV];
+    float mk[2];
+    if (grp < g.n_kv) load_trip(grp, kv, mk);
+    float qf[CH];
+    if (FRESH) {
+        const bool writer = h % g.gqa == 0 && n == 0;
+        for (int idx = tid; idx < f.N * (D / 2); idx += 1024) {
+            const int n2 = idx / (D / 2), p = idx % (D / 2);
+            const float * kr = (const float *) (f.kraw + (int64_t) hk * f.kraw_nbh + (int64_t) n2 * f.kraw_nbn);
+            float c, s;
+            rope_cs((float) f.pos[n2], (uint32_t) p, f.rp, f.ff, c, s);
+            const float x0 = kr[2 * p], x1 = kr[2 * p + 1];
+            const _Float16 y0 = (_Float16) (x0 * c - x1 * s), y1 = (_Float16) (x0 * s + x1 * c);
+            knew[n2 * D + 2 * p] = y0;
+            knew[n2 * D + 2 * p + 1] = y1;
+            if (writer) {
+                _Float16 * kd = reinterpret_cast<_Float16 *>(f.kd + (int64_t) hk * f.kd_nbh + (int64_t) n2 * f.kd_nbn);
+                kd[2 * p] = y0;
+                kd[2 * p + 1] = y1;
+            }
+        }
+        // the three preparations start on different waves (for one token: K on waves 0, V on waves 8-9, q on wave 4), so their
+        // load -> sincos -> store chains overlap instead of queueing on the same threads
+        for (int idx = (tid + 512) & 1023; idx < f.N * g.Dv; idx += 1024) {
+            const int n2 = idx / g.Dv, d = idx % g.Dv, ch = hk * g.Dv + d;
+            const _Float16 v = (_Float16) *(const float *) (f.vraw + (int64_t) ch * 4 + (int64_t) n2 * f.vraw_nbn);
+            vnew[n2 * g.Dv + d] = v;
+            if (writer) *reinterpret_cast<_Float16 *>(f.vd + (int64_t) n2 * 2 + (int64_t) ch * f.vd_nbc) = v;
+        }
+        if (const int t = tid - 256; t >= 0 && t < D / 2) {
+            const float * pq = (const float *) (g.q + (int64_t) n * g.q_nb1 + (int64_t) h * g.q_nb2);
+            float c, s;
+            rope_cs((float) f.pos[n], (uint32_t) t, f.rp, f.ff, c, s);
+            const float x0 = pq[2 * t], x1 = pq[2 * t + 1];
+            qs[2 * t] = x0 * c - x1 * s;
+            qs[2 * t + 1] = x0 * s + x1 * c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < CH; ++e) qf[e] = (float) (_Float16) qs[l8 * CH + e];
+    } else {
+        const float * pq = (const float *) (g.q + (int64_t) n * g.q_nb1 + (int64_t) h * g.q_nb2) + l8 * CH;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) qf[e] = (float) (_Float16) pq[e];
+    }
+    float mx = -INFINITY;
+    for (int jt = grp; jt < g.n_kv; jt += 256) {
+        h16x8 kvn[2][NV];
+        float mkn[2];
+        const bool more = jt + 256 < g.n_kv;
+        if (more) load_trip(jt + 256, kvn, mkn);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int j = j0 + r * 128;
+            const int j = jt + r * 128;
+            if (FRESH && (unsigned) (j - f.j0) < (unsigned) f.N) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) kv[r][c] = *(const h16x8 *) &knew[(j - f.j0) * D + l8 * CH + c * 8];
+            }
             float s = 0.0f;
 #pragma unroll
             for (int c = 0; c < NV; ++c)
@@ -658,6 +731,14 @@ attn_decode_kernel(const AttnArgs g) {
             if (j < g.n_kv) {
                 if (l8 == 0) sc[j] = s;
                 mx = fmaxf(mx, s);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) kv[r][c] = kvn[r][c];
+                mk[r] = mkn[r];
             }
         }
     }
@@ -683,6 +764,11 @@ attn_decode_kernel(const AttnArgs g) {
             for (int r = 0; r < 4; ++r) {
                 const int d = d0 + 16 * r < g.Dv ? d0 + 16 * r : d0;
                 vv[r] = *(const h16x8 *) (pv + (int64_t) d * g.v_nb1 + (int64_t) j * 2);
+                if (FRESH && j + 8 > f.j0 && j < f.j0 + f.N) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if ((unsigned) (j + e - f.j0) < (unsigned) f.N) vv[r][e] = vnew[(j + e - f.j0) * g.Dv + d];
+                }
             }
             float p[8];
 #pragma unroll
@@ -1231,12 +1317,13 @@ int qmm_attn_decode(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, c
     const dim3 grid((unsigned) g.H, (unsigned) q->ne[1]);
     const size_t lds = (size_t) g.n_kv * 4;
     hipStream_t st = ctx->s(stream);
+    const AttnFresh none{};
     if (g.D == 64) {
-        hipLaunchKernelGGL((attn_decode_kernel<64>), grid, dim3(1024), lds, st, g);
+        hipLaunchKernelGGL((attn_decode_kernel<64, false>), grid, dim3(1024), lds, st, g, none);
     } else if (g.D == 128) {
-        hipLaunchKernelGGL((attn_decode_kernel<128>), grid, dim3(1024), lds, st, g);
+        hipLaunchKernelGGL((attn_decode_kernel<128, false>), grid, dim3(1024), lds, st, g, none);
     } else {
-        hipLaunchKernelGGL((attn_decode_kernel<256>), grid, dim3(1024), lds, st, g);
+        hipLaunchKernelGGL((attn_decode_kernel<256, false>), grid, dim3(1024), lds, st, g, none);
     }
     HIP_TRY(hipGetLastError());
     return QMM_OK;
@@ -1311,6 +1398,64 @@ int qmm_attn_prefill(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, 
         auto kern = attn_prefill_kernel<64>;
         if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, N);
+    }
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+int qmm_attn_decode_rope_supported(const qmm_tensor * q, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * q_rope,
+                                   const qmm_tensor * k_new, const qmm_tensor * k_store, const qmm_tensor * v_new, const qmm_tensor * v_store,
+                                   const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask, const qmm_tensor * dst, int64_t j0) {
+    if (!q || !pos || !q_rope || !k_new || !k_store || !v_new || !v_store || !k || !v || !mask || !dst) return 0;
+    // q [D, H, N] un-roped (q_rope: the ROPE node, for its op_params); the permuted view of it is what qmm_attn_decode takes
+    qmm_tensor qp = *q;
+    qp.ne[1] = q->ne[2]; qp.ne[2] = q->ne[1]; qp.nb[1] = q->nb[2]; qp.nb[2] = q->nb[1];
+    if (!qmm_attn_decode_supported(&qp, k, v, mask, dst)) return 0;
+    if (!qmm_rope_kv_store_supported(q, pos, ff, q_rope, k_new, k_store, v_new, v_store)) return 0;
+    const int64_t D = k->ne[0], N = q->ne[2], Hk = k->ne[2], Dv = v->ne[1], n_kv = k->ne[1];
+    if (q_rope->op_params[2] != 0 || q_rope->op_params[1] != D || D > 128) return 0;                 // normal mode over the whole head
+    if (k_new->ne[0] != D || k_new->ne[1] != Hk || k_new->ne[2] != N || k_new->ne[3] != 1 || k_new->nb[0] != 4) return 0;
+    if (k_store->nb[0] != 2 || k_store->nb[1] % 2 || k_store->nb[2] % 2) return 0;
+    // v_new is v_cur^T [N, Dv * Hk] (element (n, c) at n * nb0 + c * nb1), v_store the transposed cache view [N, Dv * Hk]
+    if (v_new->ne[0] != N || v_new->ne[1] != Dv * Hk || v_new->ne[2] != 1 || v_new->ne[3] != 1 || v_new->nb[1] != 4) return 0;
+    if (v_store->ne[0] != N || v_store->ne[1] != Dv * Hk || v_store->nb[0] != 2 || v_store->nb[1] % 2) return 0;
+    if (j0 < 0 || j0 + N > n_kv) return 0;
+    return 1;
+}
+
+int qmm_attn_decode_rope(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * q_rope,
+                         const qmm_tensor * k_new, const qmm_tensor * k_store, const qmm_tensor * v_new, const qmm_tensor * v_store,
+                         const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask, const qmm_tensor * dst, float scale, int64_t j0,
+                         void * stream) {
+    if (!ctx || !qmm_attn_decode_rope_supported(q, pos, ff, q_rope, k_new, k_store, v_new, v_store, k, v, mask, dst, j0))
+        return fail(QMM_EUNSUPPORTED, "qmm_attn_decode_rope: operands not supported");
+    if ((uintptr_t) k->data % 16 || (uintptr_t) v->data % 16) return fail(QMM_EINVAL, "qmm_attn_decode_rope: K / V must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    AttnArgs g;
+    g.q = (const char *) q->data; g.k = (const char *) k->data; g.v = (const char *) v->data; g.mask = (const char *) mask->data; g.dst = (char *) dst->data;
+    g.q_nb1 = q->nb[2]; g.q_nb2 = q->nb[1];                                  // token stride, head stride of the un-permuted q
+    g.k_nb1 = k->nb[1]; g.k_nb2 = k->nb[2]; g.v_nb1 = v->nb[1]; g.v_nb2 = v->nb[2];
+    g.m_nb1 = mask->nb[1]; g.d_nb1 = dst->nb[1];
+    g.D = (int32_t) k->ne[0]; g.Dv = (int32_t) v->ne[1]; g.n_kv = (int32_t) k->ne[1]; g.H = (int32_t) q->ne[1]; g.gqa = (int32_t) (q->ne[1] / k->ne[2]);
+    g.scale = scale;
+    AttnFresh f;
+    f.kraw = (const char *) k_new->data; f.vraw = (const char *) v_new->data; f.kd = (char *) k_store->data; f.vd = (char *) v_store->data;
+    f.pos = (const int32_t *) pos->data; f.ff = ff ? (const float *) ff->data : nullptr;
+    f.kraw_nbh = k_new->nb[1]; f.kraw_nbn = k_new->nb[2]; f.vraw_nbn = v_new->nb[0];
+    f.kd_nbh = k_store->nb[1]; f.kd_nbn = k_store->nb[2]; f.vd_nbc = v_store->nb[1];
+    f.rp = rope_params(q_rope);
+    f.N = (int32_t) q->ne[2]; f.j0 = (int32_t) j0;
+    const dim3 grid((unsigned) g.H, (unsigned) f.N);
+    const size_t lds = (size_t) g.n_kv * 4 + (size_t) g.D * 4 + (size_t) f.N * (g.D + g.Dv) * 2;
+    hipStream_t st = ctx->s(stream);
+    if (g.D == 64) {
+        auto kern = attn_decode_kernel<64, true>;
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, g, f);
+    } else {
+        auto kern = attn_decode_kernel<128, true>;
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, g, f);
     }
     HIP_TRY(hipGetLastError());
     return QMM_OK;

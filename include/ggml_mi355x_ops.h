@@ -95,6 +95,20 @@ QMM_API int qmm_rope_kv_store_supported(const qmm_tensor * q, const qmm_tensor *
 QMM_API int qmm_rope_kv_store(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * q_dst,
                               const qmm_tensor * k, const qmm_tensor * k_dst, const qmm_tensor * v, const qmm_tensor * v_dst, void * stream);
 
+/* qmm_rope_kv_store and qmm_attn_decode as ONE launch for a batch of up to 8 tokens (normal-mode RoPE over the whole head,
+ * D <= 128): q [D, H, N] arrives un-roped (q_rope: the ROPE node's descriptor, for its op_params), k_new [D, H_kv, N] and
+ * v_new (v_cur^T, [N, Dv * H_kv]) are the batch's projections, k_store / v_store where qmm_rope_kv_store would put them, k / v the
+ * cache views the attention reads, j0 the cache row of the batch's first token.  Every workgroup forms the new rows it needs
+ * itself and takes them from LDS, so nothing reads rows j0 .. j0 + N of the cache while one workgroup per kv head stores them. */
+QMM_API int qmm_attn_decode_rope_supported(const qmm_tensor * q, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * q_rope,
+                                           const qmm_tensor * k_new, const qmm_tensor * k_store, const qmm_tensor * v_new,
+                                           const qmm_tensor * v_store, const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask,
+                                           const qmm_tensor * dst, int64_t j0);
+QMM_API int qmm_attn_decode_rope(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * q_rope,
+                                 const qmm_tensor * k_new, const qmm_tensor * k_store, const qmm_tensor * v_new, const qmm_tensor * v_store,
+                                 const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask, const qmm_tensor * dst, float scale,
+                                 int64_t j0, void * stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -259,3 +259,65 @@ def test_attn_prefill_one_launch(qmm, n_tok, n_kv, d):
         # tokens early in the prompt have few, large probabilities: one flipped f16 rounding of p ~ 0.5 moves an output by 2.4e-4
         assert rel_rms(got[:, hh], want) < 2e-3, (hh, n_tok, n_kv)
         assert np.sqrt(np.mean((got[:, hh] - want) ** 2) / np.mean(want ** 2)) < 1e-4
+
+
+@pytest.mark.parametrize("n_tok,j0,d", [(1, 100, 128), (3, 45, 128), (8, 0, 64), (2, 254, 128)])
+def test_attn_decode_rope_one_launch(qmm, n_tok, j0, d):
+    """rope(q), rope(k) -> K cache, v -> V cache and the attention over the updated cache as ONE launch: the result and both
+    caches against the two-step numpy reference (the new rows are used from LDS, never read back from the cache)"""
+    from ggml_hexagon_amd import capi
+    rng = np.random.default_rng(900 + n_tok + j0)
+    h, hk, n_ctx = 8, 2, 320
+    n_kv = (j0 + n_tok + 31) // 32 * 32
+    q = rng.normal(0, 1, (n_tok, h, d)).astype(np.float32)
+    k = rng.normal(0, 1, (n_tok, hk, d)).astype(np.float32)
+    v = rng.normal(0, 1, (n_tok, hk * d)).astype(np.float32)
+    pos = np.arange(j0, j0 + n_tok, dtype=np.int32)
+    kc = np.zeros((n_ctx, hk, d), np.float16)
+    vc = np.zeros((hk * d, n_ctx), np.float16)
+    kc[:j0] = rng.normal(0, 1, (j0, hk, d)).astype(np.float16)
+    vc[:, :j0] = rng.normal(0, 1, (hk * d, j0)).astype(np.float16)
+    kc[j0:j0 + n_tok] = 77.0                     # stale garbage where the new rows go: must never be read
+    vc[:, j0:j0 + n_tok] = -55.0
+    mask = np.full((64, n_kv), -np.inf, np.float32)
+    for t in range(n_tok):
+        mask[t, :j0 + t + 1] = 0.0
+    freq_base = 10000.0
+    theta_scale = np.float32(np.float32(freq_base) ** np.float32(-2.0 / d))
+    scale = 1.0 / np.sqrt(d)
+    dq, dk, dv, dpos, dkc, dvc, dm = dev(q), dev(k), dev(v), dev(pos), dev(kc), dev(vc), dev(mask)
+    out = torch.empty((n_tok, h * d), device="cuda")
+    params = [0, d, 0, 0, 8192, f2i(freq_base), f2i(1.0), f2i(0.0), f2i(1.0), f2i(32.0), f2i(1.0)]
+    M = capi.QmmTensor.make
+    tq = M(F32, [d, h, n_tok], data=dq.data_ptr())
+    tqr = M(F32, [d, h, n_tok], data=dq.data_ptr(), op_params=params)
+    tkn = M(F32, [d, hk, n_tok], data=dk.data_ptr())
+    tks = M(F16, [d, hk, n_tok], data=dkc.data_ptr() + j0 * hk * d * 2)
+    tvn = M(F32, [n_tok, hk * d], nb=[hk * d * 4, 4, 4 * n_tok * hk * d, 4 * n_tok * hk * d], data=dv.data_ptr())
+    tvs = M(F16, [n_tok, hk * d], nb=[2, n_ctx * 2, n_ctx * 2 * hk * d, n_ctx * 2 * hk * d], data=dvc.data_ptr() + j0 * 2)
+    tk = M(F16, [d, n_kv, hk], nb=[2, hk * d * 2, d * 2, n_ctx * hk * d * 2], data=dkc.data_ptr())
+    tv = M(F16, [n_kv, d, hk], nb=[2, n_ctx * 2, n_ctx * d * 2, n_ctx * d * hk * 2], data=dvc.data_ptr())
+    tm = M(F32, [n_kv, 64], data=dm.data_ptr())
+    td = M(F32, [h * d, n_tok], data=out.data_ptr())
+    r = lambda t: capi.C.byref(t)
+    qmm._chk(qmm.lib.qmm_attn_decode_rope(qmm.ctx, r(tq), r(M(I32, [n_tok], data=dpos.data_ptr())), None, r(tqr), r(tkn), r(tks), r(tvn), r(tvs),
+                                          r(tk), r(tv), r(tm), r(td), scale, j0, qmm._stream()))
+    want_k = rope_ref(k, pos, d, theta_scale).astype(np.float16)
+    kc2, vc2 = dkc.cpu().numpy(), dvc.cpu().numpy()
+    assert np.max(np.abs(kc2[j0:j0 + n_tok].astype(np.float32) - want_k.astype(np.float32))) < 4e-3
+    assert np.array_equal(kc2[:j0], kc[:j0]) and not kc2[j0 + n_tok:].any()
+    assert np.array_equal(vc2[:, j0:j0 + n_tok], v.T.astype(np.float16)) and np.array_equal(vc2[:, :j0], vc[:, :j0])
+    # reference attention over the reference caches
+    kr, vr = kc.copy(), vc.copy()
+    kr[j0:j0 + n_tok] = want_k
+    vr[:, j0:j0 + n_tok] = v.T.astype(np.float16)
+    qh = rope_ref(q, pos, d, theta_scale).astype(np.float16).astype(np.float64)            # [n_tok, h, d]
+    got = out.cpu().numpy().reshape(n_tok, h, d)
+    for hh in range(h):
+        g = hh // (h // hk)
+        s = qh[:, hh] @ kr[:n_kv, g].astype(np.float64).T * np.float32(scale) + mask[:n_tok]
+        p = np.exp(s - s.max(axis=1, keepdims=True))
+        p = (p / p.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float16).astype(np.float64)
+        want = p @ vr[g * d:(g + 1) * d, :n_kv].astype(np.float64).T
+        assert rel_rms(got[:, hh], want) < 3e-3, (hh, n_tok, j0)                        # f16 roundings of the roped q / k can flip
+        assert np.sqrt(np.mean((got[:, hh] - want) ** 2) / np.mean(want ** 2)) < 5e-4

@@ -38,9 +38,10 @@ def gguf(request, tmp_path_factory):
     return str(path)
 
 
-@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("fuse", ["1", "0", "attn_rope"])
 def test_logits_match_cpu_backend_matvec_path(gguf, fuse):
-    r = run("compare", "--gguf", gguf, "-p", "8", "-n", "8", "-t", "8", env={"GGML_MI355X_FUSE": fuse})
+    env = {"GGML_MI355X_ATTN_ROPE": "1"} if fuse == "attn_rope" else {"GGML_MI355X_FUSE": fuse}      # attn_rope: the opt-in single launch
+    r = run("compare", "--gguf", gguf, "-p", "8", "-n", "8", "-t", "8", env=env)
     print(r)
     assert "MI355X0" in r["devices"]
     assert r["worst_nmse"] < 5e-3, r
