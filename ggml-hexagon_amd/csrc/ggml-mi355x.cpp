@@ -839,7 +839,8 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         for (int i = 0; i + 1 < cgraph->n_nodes; ++i) {
             const ggml_tensor * n0 = cgraph->nodes[i];
             if (n0->op == GGML_OP_RMS_NORM || (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU) ||
-                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT || n0->op == GGML_OP_ROPE || n0->op == GGML_OP_MUL)
+                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT || n0->op == GGML_OP_ROPE || n0->op == GGML_OP_MUL ||
+                n0->op == GGML_OP_GET_ROWS || n0->op == GGML_OP_SUM_ROWS)
                 rd.push_back({ n0, 0, -1, true });
         }
         if (!rd.empty()) {
@@ -995,6 +996,39 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                                 return GGML_STATUS_FAILED;
                             }
                             done[jc] = 1;
+                            continue;
+                        }
+                    }
+                }
+            }
+            if (node->op == GGML_OP_SOFT_MAX && !node->src[1] && node->ne[0] <= 64 && node->ne[2] == 1 && node->ne[3] == 1 && !GGML_MI355X_FUSE_OFF()) {
+                // the MoE router behind its logits (build_moe_ffn): soft_max -> argsort (top_k view) -> get_rows -> sum_rows -> div
+                float scale, max_bias;
+                memcpy(&scale, (const float *) node->op_params + 0, sizeof(float));
+                memcpy(&max_bias, (const float *) node->op_params + 1, sizeof(float));
+                int idx[4], k = 0;
+                for (int j = i + 1; j < n_nodes && j <= i + 2 * LOOKAHEAD && k < 4; ++j) {
+                    if (done[j] || is_noop(cgraph->nodes[j])) continue;
+                    idx[k++] = j;
+                }
+                const auto root = [](const ggml_tensor * t) { return t->view_src ? t->view_src : t; };
+                if (k == 4 && scale == 1.0f && max_bias == 0.0f) {
+                    ggml_tensor * as = cgraph->nodes[idx[0]], * gr = cgraph->nodes[idx[1]], * sr = cgraph->nodes[idx[2]], * dv = cgraph->nodes[idx[3]];
+                    const auto * ri = info(node), * rg = info(gr), * rs = info(sr);
+                    if (as->op == GGML_OP_ARGSORT && as->src[0] == node && as->op_params[0] == GGML_SORT_ORDER_DESC &&
+                        gr->op == GGML_OP_GET_ROWS && root(gr->src[0]) == node && gr->src[0]->ne[0] == 1 && root(gr->src[1]) == as &&
+                        gr->src[1]->data == as->data && gr->src[1]->nb[1] == as->nb[1] && gr->src[1]->ne[1] == as->ne[1] &&
+                        sr->op == GGML_OP_SUM_ROWS && root(sr->src[0]) == gr && dv->op == GGML_OP_DIV && root(dv->src[0]) == gr && dv->src[1] == sr &&
+                        ri && ri->uses == 2 && rg && rg->uses == 2 && rs && rs->uses == 1 && ggml_is_contiguous(dv) && ggml_is_contiguous(gr) &&
+                        !(node->flags & GGML_TENSOR_FLAG_OUTPUT) && !(gr->flags & GGML_TENSOR_FLAG_OUTPUT) && !(sr->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                        const int64_t n_used = gr->src[1]->ne[0];
+                        const qmm_tensor lg = to_qt(node->src[0], ctx), ids = to_qt(as, ctx), w = to_qt(dv, ctx);
+                        if (qmm_moe_router_supported(&lg, &ids, &w, n_used)) {
+                            if (qmm_moe_router(ctx->dev->qmm, &lg, &ids, &w, n_used, 1, qmm_stream(ctx->dev->qmm))) {
+                                GGML_LOG_ERROR("MI355X MoE router(%s): %s\n", node->name, qmm_last_error());
+                                return GGML_STATUS_FAILED;
+                            }
+                            for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
                             continue;
                         }
                     }

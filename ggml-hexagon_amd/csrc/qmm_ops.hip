@@ -592,6 +592,53 @@ mul_mat_f16_kernel(const MmArgs g) {
     }
 }
 
+// The router of a mixture-of-experts block after its logits (build_moe_ffn, src/llama-graph.cpp:818-858), one launch instead of
+// five: probs = soft_max(logits); ids = argsort(probs, descending) (top-k = its first n_used entries); weights = probs[ids[:n_used]]
+// normalised by their sum (ggml_get_rows, ggml_sum_rows, ggml_div).  One wave per token, lane e holds expert e (n_expert <= 64).
+__global__ void __launch_bounds__(256)
+moe_router_kernel(const char * __restrict__ logits, char * __restrict__ ids, char * __restrict__ weights, const int64_t l_nb1, const int64_t i_nb1,
+                  const int64_t w_nb1, const int n_expert, const int n_used, const int n_tokens, const int normalise) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= n_tokens) return;
+    const float x = lane < n_expert ? ((const float *) (logits + (int64_t) t * l_nb1))[lane] : -INFINITY;
+    const float mx = wave_max(x);
+    const float e = lane < n_expert ? expf(x - mx) : 0.0f;
+    const float p = e * (1.0f / wave_sum(e));                      // soft_max_kernel's arithmetic: exp(x - max) * (1 / sum)
+    int rank = 0;
+    for (int j = 0; j < n_expert; ++j) {
+        const float u = __shfl(p, j, 64);
+        rank += u > p || (u == p && j < lane);
+    }
+    if (lane < n_expert) ((int32_t *) (ids + (int64_t) t * i_nb1))[rank] = lane;
+    const bool sel = lane < n_expert && rank < n_used;
+    const float sum = wave_sum(sel ? p : 0.0f);
+    if (sel) ((float *) (weights + (int64_t) t * w_nb1))[rank] = normalise ? p / sum : p;
+}
+
+// Few outputs with a long K (the MoE router at batch 1: 8 x 4096): one WORKGROUP per dst element, so K is spread over 256 threads
+// instead of 64 (the wave-per-element kernel walks K = 4096 in 64 dependent trips: 27 us per call, 0.87 ms per Mixtral token).
+__global__ void __launch_bounds__(256)
+mul_mat_dot_block_kernel(const MmArgs g) {
+    __shared__ float red[4];
+    const int i12 = blockIdx.z % g.ne12, i13 = blockIdx.z / g.ne12;
+    const int m = blockIdx.x % g.M, n = blockIdx.x / g.M;
+    const float * pa = (const float *) (g.a + (int64_t) (i12 / g.r2) * g.a_nb2 + (int64_t) (i13 / g.r3) * g.a_nb3 + (int64_t) m * g.a_nb1);
+    const float * pb = (const float *) (g.b + (int64_t) i12 * g.b_nb2 + (int64_t) i13 * g.b_nb3 + (int64_t) n * g.b_nb1);
+    float s = 0.0f;
+    if ((((uintptr_t) pa | (uintptr_t) pb) & 15) == 0) {
+        const int k4 = g.K / 4;
+        for (int k = threadIdx.x; k < k4; k += 256) {
+            const float4 x = ((const float4 *) pa)[k], y = ((const float4 *) pb)[k];
+            s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        for (int k = k4 * 4 + threadIdx.x; k < g.K; k += 256) s += pa[k] * pb[k];
+    } else {
+        for (int k = threadIdx.x; k < g.K; k += 256) s += pa[k] * pb[k];
+    }
+    s = block_reduce<false>(s, red);
+    if (threadIdx.x == 0) *(float *) (g.d + (int64_t) i12 * g.d_nb2 + (int64_t) i13 * g.d_nb3 + (int64_t) n * g.d_nb1 + (int64_t) m * 4) = s;
+}
+
 // F32 src0 (small matrices such as the MoE router ffn_gate_inp): one wave per dst element, f32 FMA, lanes stride K.
 template <typename TA>
 __global__ void __launch_bounds__(256)
@@ -1088,7 +1135,8 @@ int launch_mul_mat_f(hipStream_t st, const qmm_tensor * a, const qmm_tensor * b,
         else     hipLaunchKernelGGL((mul_mat_f16_kernel<false>), grid, dim3(256), 0, st, g);
     } else {
         const int64_t e = (int64_t) g.M * g.N;
-        hipLaunchKernelGGL((mul_mat_dot_kernel<float>), dim3((unsigned) ((e + 3) / 4), 1, batch), dim3(256), 0, st, g);
+        if (e <= 2048 && g.K >= 1024) hipLaunchKernelGGL(mul_mat_dot_block_kernel, dim3((unsigned) e, 1, batch), dim3(256), 0, st, g);
+        else                          hipLaunchKernelGGL((mul_mat_dot_kernel<float>), dim3((unsigned) ((e + 3) / 4), 1, batch), dim3(256), 0, st, g);
     }
     HIP_TRY(hipGetLastError());
     return QMM_OK;
@@ -1457,6 +1505,26 @@ int qmm_attn_decode_rope(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor *
         if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, g, f);
     }
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+int qmm_moe_router_supported(const qmm_tensor * logits, const qmm_tensor * ids, const qmm_tensor * weights, int64_t n_used) {
+    if (!logits || !ids || !weights || logits->type != G_F32 || ids->type != G_I32 || weights->type != G_F32) return 0;
+    const int64_t E = logits->ne[0], N = logits->ne[1];
+    if (E < 1 || E > 64 || n_used < 1 || n_used > E || N < 1 || N >= ((int64_t) 1 << 30)) return 0;
+    if (logits->ne[2] != 1 || logits->ne[3] != 1 || ids->ne[0] != E || ids->ne[1] != N || ids->ne[2] != 1 || ids->ne[3] != 1) return 0;
+    if (weights->ne[0] * weights->ne[1] * weights->ne[2] * weights->ne[3] != n_used * N) return 0;
+    return logits->nb[0] == 4 && ids->nb[0] == 4 && weights->nb[0] == 4 && logits->nb[1] % 4 == 0 && ids->nb[1] % 4 == 0;
+}
+
+int qmm_moe_router(qmm_ctx * ctx, const qmm_tensor * logits, const qmm_tensor * ids, const qmm_tensor * weights, int64_t n_used, int normalise,
+                   void * stream) {
+    if (!ctx || !qmm_moe_router_supported(logits, ids, weights, n_used)) return fail(QMM_EUNSUPPORTED, "qmm_moe_router: operands not supported");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int N = (int) logits->ne[1];
+    hipLaunchKernelGGL(moe_router_kernel, dim3((N + 3) / 4), dim3(256), 0, ctx->s(stream), (const char *) logits->data, (char *) ids->data,
+                       (char *) weights->data, logits->nb[1], ids->nb[1], (int64_t) n_used * 4, (int) logits->ne[0], (int) n_used, N, normalise);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }

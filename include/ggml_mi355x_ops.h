@@ -95,6 +95,14 @@ QMM_API int qmm_rope_kv_store_supported(const qmm_tensor * q, const qmm_tensor *
 QMM_API int qmm_rope_kv_store(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * pos, const qmm_tensor * ff, const qmm_tensor * q_dst,
                               const qmm_tensor * k, const qmm_tensor * k_dst, const qmm_tensor * v, const qmm_tensor * v_dst, void * stream);
 
+/* The router of a mixture-of-experts block behind its logits (build_moe_ffn, src/llama-graph.cpp:818-858) as one launch:
+ *   ids     i32 [n_expert, n_tokens] = argsort(soft_max(logits), descending); its first n_used entries per row are ggml_top_k
+ *   weights f32 [n_used * n_tokens] contiguous = the selected probabilities, divided by their sum when `normalise` (norm_w)
+ * logits f32 [n_expert <= 64, n_tokens]. */
+QMM_API int qmm_moe_router_supported(const qmm_tensor * logits, const qmm_tensor * ids, const qmm_tensor * weights, int64_t n_used);
+QMM_API int qmm_moe_router(qmm_ctx * ctx, const qmm_tensor * logits, const qmm_tensor * ids, const qmm_tensor * weights, int64_t n_used,
+                           int normalise, void * stream);
+
 /* qmm_rope_kv_store and qmm_attn_decode as ONE launch for a batch of up to 8 tokens (normal-mode RoPE over the whole head,
  * D <= 128): q [D, H, N] arrives un-roped (q_rope: the ROPE node's descriptor, for its op_params), k_new [D, H_kv, N] and
  * v_new (v_cur^T, [N, Dv * H_kv]) are the batch's projections, k_store / v_store where qmm_rope_kv_store would put them, k / v the

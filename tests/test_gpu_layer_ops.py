@@ -321,3 +321,24 @@ def test_attn_decode_rope_one_launch(qmm, n_tok, j0, d):
         want = p @ vr[g * d:(g + 1) * d, :n_kv].astype(np.float64).T
         assert rel_rms(got[:, hh], want) < 3e-3, (hh, n_tok, j0)                        # f16 roundings of the roped q / k can flip
         assert np.sqrt(np.mean((got[:, hh] - want) ** 2) / np.mean(want ** 2)) < 5e-4
+
+
+@pytest.mark.parametrize("n_tok,n_expert,n_used", [(1, 8, 2), (77, 8, 2), (5, 64, 6), (512, 16, 4)])
+def test_moe_router_one_launch(qmm, n_tok, n_expert, n_used):
+    """soft_max -> argsort(desc) -> top-k weights / their sum (build_moe_ffn's router) in one launch, against numpy"""
+    from ggml_hexagon_amd import capi
+    rng = np.random.default_rng(n_tok * 3 + n_expert)
+    logits = rng.normal(0, 2, (n_tok, n_expert)).astype(np.float32)
+    dl = dev(logits)
+    ids = torch.full((n_tok, n_expert), -1, dtype=torch.int32, device="cuda")
+    w = torch.zeros((n_tok, n_used), device="cuda")
+    M = capi.QmmTensor.make
+    r = lambda t: capi.C.byref(t)
+    qmm._chk(qmm.lib.qmm_moe_router(qmm.ctx, r(M(F32, [n_expert, n_tok], data=dl.data_ptr())), r(M(I32, [n_expert, n_tok], data=ids.data_ptr())),
+                                    r(M(F32, [n_used, n_tok], data=w.data_ptr())), n_used, 1, qmm._stream()))
+    e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    p = e / e.sum(axis=1, keepdims=True)
+    order = np.argsort(-p, axis=1, kind="stable")
+    assert np.array_equal(ids.cpu().numpy(), order.astype(np.int32))
+    sel = np.take_along_axis(p, order[:, :n_used], axis=1)
+    assert np.allclose(w.cpu().numpy(), sel / sel.sum(axis=1, keepdims=True), rtol=2e-6, atol=1e-7)
