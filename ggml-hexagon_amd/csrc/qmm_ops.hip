@@ -833,6 +833,109 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
     }
 }
 
+// Long caches at batch <= 8: one workgroup per (head, token) walks the whole cache (45 us per layer at n_kv = 4160).  From
+// n_kv = 1024 the kv range is cut into S pieces, one workgroup each (grid z), which leave (max, sum, unnormalised output row) in
+// the workspace; attn_combine_kernel merges them with the usual rescaling.  p stays f32 here (the single-workgroup kernel and
+// the CPU round the normalised p to f16 before the product with V): results agree to ~2^-11 relative.
+template <int D>
+__global__ void __launch_bounds__(1024)
+attn_decode_split_kernel(const AttnArgs g, float * __restrict__ part, const int S, const int chunk) {
+    extern __shared__ float sc[];                       // this piece's scores, then exp(score - max)
+    __shared__ float red[16];
+    const int h = blockIdx.x, n = blockIdx.y, sp = blockIdx.z, hk = h / g.gqa;
+    const int j_lo = sp * chunk, j_hi = min(g.n_kv, j_lo + chunk), len = max(j_hi - j_lo, 0);
+    const int tid = threadIdx.x, l8 = tid & 7, grp = tid >> 3;
+    constexpr int CH = D / 8, NV = CH / 8;
+    float qf[CH];
+    {
+        const float * pq = (const float *) (g.q + (int64_t) n * g.q_nb1 + (int64_t) h * g.q_nb2) + l8 * CH;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) qf[e] = (float) (_Float16) pq[e];
+    }
+    const float * pm = (const float *) (g.mask + (int64_t) n * g.m_nb1);
+    const char *  pk = g.k + (int64_t) hk * g.k_nb2 + (int64_t) l8 * CH * 2;
+    float mx = -INFINITY;
+    for (int jt = j_lo + grp; jt < j_hi; jt += 256) {
+        h16x8 kv[2][NV];
+        float mk[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = jt + r * 128, jc = j < j_hi ? j : jt;
+            const h16x8 * row = (const h16x8 *) (pk + (int64_t) jc * g.k_nb1);
+#pragma unroll
+            for (int c = 0; c < NV; ++c) kv[r][c] = row[c];
+            mk[r] = pm[jc];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = jt + r * 128;
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float) kv[r][c][e] * qf[c * 8 + e];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s = s * g.scale + mk[r];
+            if (j < j_hi) {
+                if (l8 == 0) sc[j - j_lo] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+    }
+    mx = block_reduce<true>(mx, red);
+    float sum = 0.0f;
+    for (int j = tid; j < len; j += 1024) {
+        const float e = mx == -INFINITY ? 0.0f : expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = block_reduce<false>(sum, red);                // its barriers publish sc[]
+    const int lane = tid & 63, wave = tid >> 6;
+    float * po = part + ((int64_t) (h * gridDim.y + n) * S + sp) * (g.Dv + 2);
+    if (tid == 0) { po[0] = mx; po[1] = sum; }
+    const char * pv = g.v + (int64_t) hk * g.v_nb2;
+    for (int d0 = wave; d0 < g.Dv; d0 += 64) {
+        float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        for (int j = lane * 8; j < len; j += 512) {
+            h16x8 vv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = d0 + 16 * r < g.Dv ? d0 + 16 * r : d0;
+                vv[r] = *(const h16x8 *) (pv + (int64_t) d * g.v_nb1 + (int64_t) (j_lo + j) * 2);
+            }
+            float p[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p[e] = j + e < len ? sc[j + e] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[r] += (float) vv[r][e] * p[e];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = wave_sum(acc[r]);
+            if (lane == 0 && d0 + 16 * r < g.Dv) po[2 + d0 + 16 * r] = t;
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+attn_combine_kernel(const float * __restrict__ part, char * __restrict__ dst, const int64_t d_nb1, const int Dv, const int S) {
+    const int h = blockIdx.x, n = blockIdx.y;
+    const float * pp = part + (int64_t) (h * gridDim.y + n) * S * (Dv + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < S; ++s) M = fmaxf(M, pp[(int64_t) s * (Dv + 2)]);
+    float L = 0.0f;
+    for (int s = 0; s < S; ++s) L += pp[(int64_t) s * (Dv + 2) + 1] * expf(pp[(int64_t) s * (Dv + 2)] - M);
+    float * out = (float *) (dst + (int64_t) n * d_nb1) + (int64_t) h * Dv;
+    for (int d = threadIdx.x; d < Dv; d += 256) {
+        float o = 0.0f;
+        for (int s = 0; s < S; ++s) o += pp[(int64_t) s * (Dv + 2) + 2 + d] * expf(pp[(int64_t) s * (Dv + 2)] - M);
+        out[d] = o / L;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ attention, prompt batches
 // The same chain for a prompt batch whose scores fit LDS (n_kv <= 512: llama-bench's pp512), one workgroup of 4 waves per
 // (64 tokens, head).  The three-launch form is bound by the f32 score tensor (33 MB per layer at 512 x 512 x 32: written by KQ,
@@ -1365,6 +1468,23 @@ int qmm_attn_decode(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, c
     const dim3 grid((unsigned) g.H, (unsigned) q->ne[1]);
     const size_t lds = (size_t) g.n_kv * 4;
     hipStream_t st = ctx->s(stream);
+    static const bool split_on = [] { const char * e = getenv("GGML_MI355X_ATTN_SPLIT"); return !(e && atoi(e) == 0); }();
+    if (split_on && g.n_kv >= 1024 && g.D <= 128) {
+        // kv range over S workgroups per (head, token), then the merge (long caches: one workgroup per head is latency-bound)
+        const int S = g.n_kv / 256 < 16 ? g.n_kv / 256 : 16;
+        const int chunk = ((g.n_kv + S - 1) / S + 7) / 8 * 8;
+        const int N = (int) q->ne[1];
+        const size_t bytes = (size_t) g.H * N * S * (g.Dv + 2) * sizeof(float);
+        int rc = ensure_ws(ctx, bytes);
+        if (rc) return rc;
+        float * part = (float *) ctx->ws;
+        const dim3 sgrid((unsigned) g.H, (unsigned) N, (unsigned) S);
+        if (g.D == 64) hipLaunchKernelGGL((attn_decode_split_kernel<64>), sgrid, dim3(1024), (size_t) chunk * 4, st, g, part, S, chunk);
+        else           hipLaunchKernelGGL((attn_decode_split_kernel<128>), sgrid, dim3(1024), (size_t) chunk * 4, st, g, part, S, chunk);
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned) g.H, (unsigned) N), dim3(256), 0, st, (const float *) part, g.dst, g.d_nb1, g.Dv, S);
+        HIP_TRY(hipGetLastError());
+        return QMM_OK;
+    }
     const AttnFresh none{};
     if (g.D == 64) {
         hipLaunchKernelGGL((attn_decode_kernel<64, false>), grid, dim3(1024), lds, st, g, none);

@@ -188,7 +188,7 @@ def test_rope_kv_store_one_launch(qmm, n_tok):
     assert not vc[:, :kv_head].any() and not vc[:, kv_head + n_tok:].any()
 
 
-@pytest.mark.parametrize("n_tok,n_kv,d", [(1, 640, 128), (3, 96, 128), (1, 32, 64), (8, 1024, 128)])
+@pytest.mark.parametrize("n_tok,n_kv,d", [(1, 640, 128), (3, 96, 128), (1, 32, 64), (8, 1024, 128), (2, 4160, 128), (1, 1056, 64), (3, 16384, 128)])
 def test_attn_decode_one_launch(qmm, n_tok, n_kv, d):
     """KQ -> soft_max(scale, mask) -> KQV -> merged heads, grouped-query, against f64 numpy with the CPU's f16 roundings of q and p"""
     from ggml_hexagon_amd import capi
@@ -220,8 +220,8 @@ def test_attn_decode_one_launch(qmm, n_tok, n_kv, d):
         p = (p / p.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float16).astype(np.float64)
         want = p @ vc[g, :, :n_kv].astype(np.float64).T
         # p is rounded to f16 (as the CPU's F16 vec_dot does): an f32-vs-f64 difference in exp / sum can flip such a rounding,
-        # one flip is 2^-11 of one probability
-        assert rel_rms(got[:, hh], want) < 5e-4, (hh, n_tok, n_kv)
+        # one flip is 2^-11 of one probability.  From n_kv = 1024 the kv range is split over workgroups and p stays f32.
+        assert rel_rms(got[:, hh], want) < (5e-4 if n_kv < 1024 else 1.5e-3), (hh, n_tok, n_kv)
 
 
 @pytest.mark.parametrize("n_tok,n_kv,d", [(512, 512, 128), (70, 96, 128), (33, 64, 64), (200, 480, 128)])
