@@ -944,13 +944,20 @@ attn_combine_kernel(const float * __restrict__ part, char * __restrict__ dst, co
 //   2. soft_max per row in LDS       a wave per row, the row in registers; p is stored back as f16 in the row's own bytes
 //   3. O = P V                       V^T tiles of 32 columns through LDS, P fragments read from the score rows
 // q and p are rounded to f16 as on the CPU path (F16 vec_dot); the result goes out in the merged-heads layout.
-constexpr int AP_TN = 64, AP_KT = 64;                                      // tokens per workgroup, K rows / V columns per tile
+constexpr int AP_TN = 64, AP_KT = 64, AP_CH = 512;                        // tokens per workgroup, K rows / V columns per tile, kv columns per chunk
+// Caches longer than one chunk are walked chunk by chunk with the usual running (max, sum) per token row: the output accumulators
+// are rescaled by exp(max_old - max_new) before a chunk's P V is added and divided by the sum at the end.  With several chunks
+// p is stored unnormalised (exp(s - max), f16): against the CPU, which rounds the normalised p, results agree to f16 rounding
+// (~1e-3 of an output at worst); a cache of one chunk keeps the CPU's order of operations.
 template <int D>
 __global__ void __launch_bounds__(256)
 attn_prefill_kernel(const AttnArgs g, const int N) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ap_smem[];
-    __shared__ int tile_dead[8];                                           // kv tile fully masked for all 64 tokens (the causal upper triangle)
-    const int SP = g.n_kv + 4;                                             // score row pitch in floats: 16-byte reads of 32 rows hit distinct banks
+    __shared__ int tile_dead[AP_CH / AP_KT];                               // kv tile fully masked for all 64 tokens (the causal upper triangle)
+    __shared__ float row_max[AP_TN], row_sum[AP_TN], row_alpha[AP_TN];
+    const int CW = g.n_kv < AP_CH ? g.n_kv : AP_CH;                        // chunk width
+    const bool single = g.n_kv <= AP_CH;
+    const int SP = CW + 4;                                                 // score row pitch in floats: 16-byte reads of 32 rows hit distinct banks
     float *    S  = reinterpret_cast<float *>(ap_smem);
     _Float16 * tl = reinterpret_cast<_Float16 *>(ap_smem + (size_t) AP_TN * SP * 4);      // K tile [64][D + 8], later V tile [D][64 + 8]
     constexpr int KP = D + 8, VP = AP_KT + 8;
@@ -970,132 +977,154 @@ attn_prefill_kernel(const AttnArgs g, const int N) {
             qf[kk] = h16x8{ (_Float16) x.x, (_Float16) x.y, (_Float16) x.z, (_Float16) x.w, (_Float16) y.x, (_Float16) y.y, (_Float16) y.z, (_Float16) y.w };
         }
     }
-    // 1. scores.  A tile's K rows are requested one tile ahead, so the loads fly under the MFMAs of the current one.
-    const char * pk = g.k + (int64_t) hk * g.k_nb2;
-    constexpr int CPR = D / 8;                                             // 16-byte chunks per K row
-    h16x8 pre[NCH];
-    auto fetch_k = [&](int j0) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i, row = c / CPR, col = c % CPR;
-            pre[i] = h16x8{0};
-            if (j0 + row < g.n_kv) pre[i] = *(const h16x8 *) (pk + (int64_t) (j0 + row) * g.k_nb1 + col * 16);
-        }
-    };
-    fetch_k(0);
-    for (int j0 = 0, jt = 0; j0 < g.n_kv; j0 += AP_KT, ++jt) {
-        const int j = j0 + 32 * kw + l32;
-        float m[16];
-        int dead = 1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + 32 * tw + 8 * (r >> 2) + 4 * hh + (r & 3);
-            m[r] = j < g.n_kv ? *(const float *) (g.mask + (int64_t) (n < N ? n : N - 1) * g.m_nb1 + (int64_t) j * 4) : -INFINITY;
-            dead &= m[r] == -INFINITY;
-        }
-        dead = __syncthreads_and(dead);                                    // also: the previous tile's fragment reads are done
-        if (tid == 0) tile_dead[jt] = dead;
-        if (!dead) {
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = tid + 256 * i;
-                *(h16x8 *) &tl[(c / CPR) * KP + (c % CPR) * 8] = pre[i];
-            }
-        }
-        __syncthreads();
-        if (j0 + AP_KT < g.n_kv) fetch_k(j0 + AP_KT);
-        f32x16v acc = {0};
-        if (!dead) {
-#pragma unroll
-            for (int kk = 0; kk < D / 16; ++kk) {
-                const h16x8 kf = *(const h16x8 *) &tl[(32 * kw + l32) * KP + 16 * kk + 8 * hh];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qf[kk], kf, acc, 0, 0, 0);
-            }
-        }
-        if (j < g.n_kv) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) S[(32 * tw + 8 * (r >> 2) + 4 * hh + (r & 3)) * SP + j] = dead ? -INFINITY : acc[r] * g.scale + m[r];
-        }
-    }
-    __syncthreads();
-    // 2. soft_max: 16 rows per wave, n_kv <= 512 values = two float4 per lane
-    for (int nl = wave * 16; nl < wave * 16 + 16; ++nl) {
-        float * row = S + nl * SP;
-        float4 v[2];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int i = 4 * (lane + 64 * t);
-            v[t] = i < g.n_kv ? *(const float4 *) (row + i) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-            mx = fmaxf(fmaxf(mx, fmaxf(v[t].x, v[t].y)), fmaxf(v[t].z, v[t].w));
-        }
-        mx = wave_max(mx);
-        float sum = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            v[t].x = expf(v[t].x - mx); v[t].y = expf(v[t].y - mx); v[t].z = expf(v[t].z - mx); v[t].w = expf(v[t].w - mx);
-            sum += v[t].x + v[t].y + v[t].z + v[t].w;
-        }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        _Float16 * prow = reinterpret_cast<_Float16 *>(row);               // p as f16 over the first half of the row's own bytes
-        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int i = 4 * (lane + 64 * t);
-            if (i < g.n_kv) *(h16x4 *) (prow + i) = h16x4{ (_Float16) (v[t].x * inv), (_Float16) (v[t].y * inv), (_Float16) (v[t].z * inv), (_Float16) (v[t].w * inv) };
-        }
-    }
-    // 3. O = P V: wave (tw, kw) owns tokens 32 tw .. +32 and the d tiles kw * DT .. + DT; dead kv tiles (p = 0 for all 64 tokens)
-    //    are not even loaded
+    if (tid < AP_TN) { row_max[tid] = -INFINITY; row_sum[tid] = 0.0f; }
     constexpr int DT = D / 64;                                             // 32-wide d tiles per wave
+    constexpr int CPR = D / 8;                                             // 16-byte chunks per K row
     constexpr int VPR = AP_KT / 8;                                         // 16-byte chunks per V^T row of the tile
     f32x16v oacc[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) oacc[t] = f32x16v{0};
+    const char * pk = g.k + (int64_t) hk * g.k_nb2;
     const char * pv = g.v + (int64_t) hk * g.v_nb2;
-    auto fetch_v = [&](int j0) {
+    h16x8 pre[NCH];
+
+    for (int c0 = 0; c0 < g.n_kv; c0 += AP_CH) {
+        const int c1 = c0 + AP_CH < g.n_kv ? c0 + AP_CH : g.n_kv;          // this chunk: kv columns c0 .. c1
+        // 1. scores.  A tile's K rows are requested one tile ahead, so the loads fly under the MFMAs of the current one.
+        auto fetch_k = [&](int j0) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i, row = c / VPR, col = c % VPR;
-            pre[i] = h16x8{0};
-            if (j0 + col * 8 < g.n_kv) pre[i] = *(const h16x8 *) (pv + (int64_t) row * g.v_nb1 + (int64_t) (j0 + col * 8) * 2);
-        }
-    };
-    __syncthreads();                                                       // tile_dead and the p rows are visible to everyone
-    int jn = 0, jtn = 0;                                                   // next live tile
-    while (jn < g.n_kv && tile_dead[jtn]) { jn += AP_KT; ++jtn; }
-    if (jn < g.n_kv) fetch_v(jn);
-    while (jn < g.n_kv) {
-        const int j0 = jn;
-        jn += AP_KT; ++jtn;
-        while (jn < g.n_kv && tile_dead[jtn]) { jn += AP_KT; ++jtn; }
-        __syncthreads();                                                   // the previous tile's fragment reads are done
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + 256 * i, row = c / CPR, col = c % CPR;
+                pre[i] = h16x8{0};
+                if (j0 + row < c1) pre[i] = *(const h16x8 *) (pk + (int64_t) (j0 + row) * g.k_nb1 + col * 16);
+            }
+        };
+        fetch_k(c0);
+        int live_tiles = 0;
+        for (int j0 = c0, jt = 0; j0 < c1; j0 += AP_KT, ++jt) {
+            const int j = j0 + 32 * kw + l32;
+            float m[16];
+            int dead = 1;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i;
-            *(h16x8 *) &tl[(c / VPR) * VP + (c % VPR) * 8] = pre[i];
-        }
-        __syncthreads();
-        if (jn < g.n_kv) fetch_v(jn);
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 32 * tw + 8 * (r >> 2) + 4 * hh + (r & 3);
+                m[r] = j < c1 ? *(const float *) (g.mask + (int64_t) (n < N ? n : N - 1) * g.m_nb1 + (int64_t) j * 4) : -INFINITY;
+                dead &= m[r] == -INFINITY;
+            }
+            dead = __syncthreads_and(dead);                                // also: the previous tile's fragment reads are done
+            if (tid == 0) tile_dead[jt] = dead;
+            live_tiles += !dead;
+            if (!dead) {
 #pragma unroll
-        for (int ks = 0; ks < AP_KT / 16; ++ks) {
-            if (j0 + 16 * ks >= g.n_kv) break;
-            const h16x8 pf = *(const h16x8 *) (reinterpret_cast<const _Float16 *>(S + (32 * tw + l32) * SP) + j0 + 16 * ks + 8 * hh);
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = tid + 256 * i;
+                    *(h16x8 *) &tl[(c / CPR) * KP + (c % CPR) * 8] = pre[i];
+                }
+            }
+            __syncthreads();
+            if (j0 + AP_KT < c1) fetch_k(j0 + AP_KT);
+            f32x16v acc = {0};
+            if (!dead) {
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const h16x8 vf = *(const h16x8 *) &tl[(32 * (kw * DT + t) + l32) * VP + 16 * ks + 8 * hh];
-                oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, vf, oacc[t], 0, 0, 0);
+                for (int kk = 0; kk < D / 16; ++kk) {
+                    const h16x8 kf = *(const h16x8 *) &tl[(32 * kw + l32) * KP + 16 * kk + 8 * hh];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qf[kk], kf, acc, 0, 0, 0);
+                }
+            }
+            if (j < c1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[(32 * tw + 8 * (r >> 2) + 4 * hh + (r & 3)) * SP + j - c0] = dead ? -INFINITY : acc[r] * g.scale + m[r];
             }
         }
+        __syncthreads();
+        if (live_tiles == 0) continue;                                     // block-uniform: the whole chunk is masked for these tokens
+        // 2. soft_max step: 16 rows per wave, <= 512 values = two float4 per lane; running max / sum per row
+        const int cw = c1 - c0;
+        for (int nl = wave * 16; nl < wave * 16 + 16; ++nl) {
+            float * row = S + nl * SP;
+            float4 v[2];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int i = 4 * (lane + 64 * t);
+                v[t] = i < cw ? *(const float4 *) (row + i) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                mx = fmaxf(fmaxf(mx, fmaxf(v[t].x, v[t].y)), fmaxf(v[t].z, v[t].w));
+            }
+            const float m_old = row_max[nl], m_new = fmaxf(m_old, wave_max(mx));
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (m_new == -INFINITY) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                else { v[t].x = expf(v[t].x - m_new); v[t].y = expf(v[t].y - m_new); v[t].z = expf(v[t].z - m_new); v[t].w = expf(v[t].w - m_new); }
+                sum += v[t].x + v[t].y + v[t].z + v[t].w;
+            }
+            sum = wave_sum(sum);
+            const float alpha = m_old == -INFINITY ? 0.0f : expf(m_old - m_new);
+            if (single) {                                                  // one chunk: normalise before the f16 rounding, exactly as the CPU path does
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) { v[t].x *= inv; v[t].y *= inv; v[t].z *= inv; v[t].w *= inv; }
+                sum = 1.0f;
+            }
+            if (lane == 0) { row_max[nl] = m_new; row_sum[nl] = row_sum[nl] * alpha + sum; row_alpha[nl] = alpha; }
+            _Float16 * prow = reinterpret_cast<_Float16 *>(row);           // p as f16 over the first half of the row's own bytes
+            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int i = 4 * (lane + 64 * t);
+                if (i < cw) *(h16x4 *) (prow + i) = h16x4{ (_Float16) v[t].x, (_Float16) v[t].y, (_Float16) v[t].z, (_Float16) v[t].w };
+            }
+        }
+        __syncthreads();                                                   // tile_dead, row_alpha and the p rows are visible to everyone
+        // 3. O = alpha * O + P V: wave (tw, kw) owns tokens 32 tw .. +32 and the d tiles kw * DT .. + DT; dead kv tiles are not loaded
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] *= row_alpha[32 * tw + 8 * (r >> 2) + 4 * hh + (r & 3)];
+        auto fetch_v = [&](int j0) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + 256 * i, row = c / VPR, col = c % VPR;
+                pre[i] = h16x8{0};
+                if (j0 + col * 8 < c1) pre[i] = *(const h16x8 *) (pv + (int64_t) row * g.v_nb1 + (int64_t) (j0 + col * 8) * 2);
+            }
+        };
+        int jn = c0, jtn = 0;                                              // next live tile
+        while (jn < c1 && tile_dead[jtn]) { jn += AP_KT; ++jtn; }
+        if (jn < c1) fetch_v(jn);
+        while (jn < c1) {
+            const int j0 = jn;
+            jn += AP_KT; ++jtn;
+            while (jn < c1 && tile_dead[jtn]) { jn += AP_KT; ++jtn; }
+            __syncthreads();                                               // the previous tile's fragment reads are done
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + 256 * i;
+                *(h16x8 *) &tl[(c / VPR) * VP + (c % VPR) * 8] = pre[i];
+            }
+            __syncthreads();
+            if (jn < c1) fetch_v(jn);
+#pragma unroll
+            for (int ks = 0; ks < AP_KT / 16; ++ks) {
+                if (j0 + 16 * ks >= c1) break;
+                const h16x8 pf = *(const h16x8 *) (reinterpret_cast<const _Float16 *>(S + (32 * tw + l32) * SP) + (j0 - c0) + 16 * ks + 8 * hh);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const h16x8 vf = *(const h16x8 *) &tl[(32 * (kw * DT + t) + l32) * VP + 16 * ks + 8 * hh];
+                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, vf, oacc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                                   // the score tile and tile_dead are free for the next chunk
     }
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
         const int d = 32 * (kw * DT + t) + l32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int n = n0 + 32 * tw + 8 * (r >> 2) + 4 * hh + (r & 3);
-            if (n < N) *(float *) (g.dst + (int64_t) n * g.d_nb1 + ((int64_t) h * g.Dv + d) * 4) = oacc[t][r];
+            const int nl = 32 * tw + 8 * (r >> 2) + 4 * hh + (r & 3), n = n0 + nl;
+            if (n < N) *(float *) (g.dst + (int64_t) n * g.d_nb1 + ((int64_t) h * g.Dv + d) * 4) = oacc[t][r] / row_sum[nl];
         }
     }
 }
@@ -1535,7 +1564,7 @@ int qmm_attn_prefill_supported(const qmm_tensor * q, const qmm_tensor * k, const
     const int64_t D = k->ne[0], n_kv = k->ne[1], Hk = k->ne[2], N = q->ne[1], H = q->ne[2], Dv = v->ne[1];
     if ((D != 64 && D != 128) || Dv != D) return 0;
     if (q->ne[0] != D || v->ne[0] != n_kv || v->ne[2] != Hk || Hk <= 0 || H % Hk || q->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1) return 0;
-    if (N < 1 || N > (1 << 20) || n_kv < 32 || n_kv % 32 || n_kv > 512 || H > 65535) return 0;
+    if (N < 1 || N > (1 << 20) || n_kv < 32 || n_kv % 32 || n_kv > (1 << 20) || H > 65535) return 0;
     if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || mask->nb[0] != 4 || dst->nb[0] != 4) return 0;
     if (mask->ne[0] != n_kv || mask->ne[1] < N || dst->ne[0] != Dv * H || dst->ne[1] != N || dst->ne[2] != 1 || dst->ne[3] != 1) return 0;
     if (q->nb[1] % 16 || q->nb[2] % 16 || k->nb[1] % 16 || k->nb[2] % 16 || v->nb[1] % 16 || v->nb[2] % 16 || mask->nb[1] % 4 || dst->nb[1] % 4) return 0;
@@ -1556,7 +1585,7 @@ int qmm_attn_prefill(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, 
     const int N = (int) q->ne[1];
     const dim3 grid((unsigned) ((N + AP_TN - 1) / AP_TN), (unsigned) g.H);
     const size_t tile = (size_t) 128 * (AP_KT + 8) * 2;                      // >= K tile 64 x (D + 8) and V tile D x (64 + 8) halves, D <= 128
-    const size_t lds = (size_t) AP_TN * (g.n_kv + 4) * 4 + tile;
+    const size_t lds = (size_t) AP_TN * ((g.n_kv < AP_CH ? g.n_kv : AP_CH) + 4) * 4 + tile;
     hipStream_t st = ctx->s(stream);
     if (g.D == 128) {
         auto kern = attn_prefill_kernel<128>;

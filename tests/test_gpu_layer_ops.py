@@ -224,10 +224,11 @@ def test_attn_decode_one_launch(qmm, n_tok, n_kv, d):
         assert rel_rms(got[:, hh], want) < (5e-4 if n_kv < 1024 else 1.5e-3), (hh, n_tok, n_kv)
 
 
-@pytest.mark.parametrize("n_tok,n_kv,d", [(512, 512, 128), (70, 96, 128), (33, 64, 64), (200, 480, 128)])
+@pytest.mark.parametrize("n_tok,n_kv,d", [(512, 512, 128), (70, 96, 128), (33, 64, 64), (200, 480, 128), (300, 1024, 128), (130, 2080, 128),
+                                           (64, 576, 64)])
 def test_attn_prefill_one_launch(qmm, n_tok, n_kv, d):
-    """the same chain for a prompt batch with the scores held in LDS (n_kv <= 512): ragged token tiles, n_kv not a multiple of
-    the 64-row K tile, D = 64 and 128, grouped-query, causal-style mask"""
+    """the same chain for a prompt batch with the scores held in LDS, 512 kv columns at a time (running max / sum beyond that):
+    ragged token tiles, n_kv not a multiple of the 64-row K tile or of the chunk, D = 64 and 128, grouped-query, causal-style mask"""
     from ggml_hexagon_amd import capi
     rng = np.random.default_rng(n_kv * 7 + n_tok)
     h, hk, n_ctx = 8, 2, n_kv + 32
@@ -257,8 +258,9 @@ def test_attn_prefill_one_launch(qmm, n_tok, n_kv, d):
         p = (p / p.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float16).astype(np.float64)
         want = p @ vc[g, :, :n_kv].astype(np.float64).T
         # tokens early in the prompt have few, large probabilities: one flipped f16 rounding of p ~ 0.5 moves an output by 2.4e-4
-        assert rel_rms(got[:, hh], want) < 2e-3, (hh, n_tok, n_kv)
-        assert np.sqrt(np.mean((got[:, hh] - want) ** 2) / np.mean(want ** 2)) < 1e-4
+        # (beyond one 512-column chunk p is rounded before it is normalised: f16 rounding of the largest p instead of the normalised one)
+        assert rel_rms(got[:, hh], want) < (2e-3 if n_kv <= 512 else 6e-3), (hh, n_tok, n_kv)
+        assert np.sqrt(np.mean((got[:, hh] - want) ** 2) / np.mean(want ** 2)) < (1e-4 if n_kv <= 512 else 4e-4)
 
 
 @pytest.mark.parametrize("n_tok,j0,d", [(1, 100, 128), (3, 45, 128), (8, 0, 64), (2, 254, 128)])
