@@ -91,7 +91,8 @@ template <int T, int NTOK> __host__ __device__ inline size_t matvec_lds_bytes(in
 // adjacent rows per wave step sharing the activation reads: 66 MB at N = 1 15.3 -> 15.9 us, N = 8 unchanged; four
 // slices' loads in flight per wave on K = 14336 rows: 11.5 -> 14.7 us; two Q4_0 blocks per lane and slice: 9.4 MB
 // 6.2 -> 5.8 us but the 7B pass 743 -> 724 tok/s; nontemporal weight loads: 66 MB 15.3 -> 18.5 us.  Every variant that
-// widens a wave's window of outstanding loads loses on the long streams.)
+// widens a wave's window of outstanding loads loses on the long streams.  Once more at the end of the round: both slices of a
+// K = 4096 row requested together (iters == 2 only, long rows untouched): tg128 747 -> 738.)
 // EX: the instantiation that honours g.res / g.norm_w (qmm_mul_mat_group_ex); the plain one compiles them away, so the hot
 // path of bench.py is the kernel it was before those fields existed (with them as run-time branches: 9.17 -> 9.50 us per launch)
 template <int T, int NTOK, bool EX>
