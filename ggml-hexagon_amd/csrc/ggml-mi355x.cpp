@@ -85,7 +85,7 @@ bool GGML_MI355X_GLUE_OFF() {
     return off;
 }
 bool GGML_MI355X_ATTN_ROPE() {
-    static const bool on = [] { const char * e = getenv("GGML_MI355X_ATTN_ROPE"); return e && atoi(e) != 0; }();
+    static const bool on = [] { const char * e = getenv("GGML_MI355X_ATTN_ROPE"); return !(e && atoi(e) == 0); }();
     return on;
 }
 bool GGML_MI355X_FUSE_OFF() {
@@ -1083,9 +1083,8 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                     }
                     const qmm_tensor * pff = node->src[2] ? &ff : nullptr, * pk = jk >= 0 ? &k : nullptr, * pkd = jk >= 0 ? &kd : nullptr,
                                      * pv = jcv >= 0 ? &v : nullptr, * pvd = jcv >= 0 ? &vd : nullptr;
-                    // ... and when the attention chain follows (few tokens): rope, KV store and attention in one launch.  Opt-in
-                    // (GGML_MI355X_ATTN_ROPE=1): measured level with the two launches it replaces (15.0 us against 4.9 + 9.2 + a boundary),
-                    // its preparation phase is a serial load -> sincos -> barrier chain in front of the attention
+                    // ... and when the attention chain follows (few tokens): rope, KV store and attention in one launch
+                    // (GGML_MI355X_ATTN_ROPE=0: two launches; tg128 395 -> 403 tok/s)
                     if (jk >= 0 && jcv >= 0 && node->ne[2] <= 8 && single_use(node) && GGML_MI355X_ATTN_ROPE()) {
                         int idx[5], kq_n = 0;
                         for (int j = std::max(jck, jcv) + 1; j < n_nodes && j <= i + 4 * LOOKAHEAD && kq_n < 5; ++j) {

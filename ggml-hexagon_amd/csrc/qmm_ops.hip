@@ -803,32 +803,46 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
     const int lane = tid & 63, wave = tid >> 6;
     float * out = (float *) (g.dst + (int64_t) n * g.d_nb1) + (int64_t) h * g.Dv;
     const char * pv = g.v + (int64_t) hk * g.v_nb2;
+    // FRESH: the probabilities of the batch's own positions are set aside and zeroed in sc[], so the main loop runs over the
+    // (stale, finite) cache values of those columns with weight 0 and the new V rows come in as a rank-N update at the end
+    float pfresh[8];
+    if (FRESH) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pfresh[i] = i < f.N ? sc[f.j0 + i] : 0.0f;
+        __syncthreads();
+        if (tid < f.N) sc[f.j0 + tid] = 0.0f;
+        __syncthreads();
+    }
     for (int d0 = wave; d0 < g.Dv; d0 += 64) {          // four V rows (d0, +16, +32, +48) per trip
         float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-        for (int j = lane * 8; j < g.n_kv; j += 512) {
-            h16x8 vv[4];
+        for (int j = lane * 8; j < g.n_kv; j += 1024) {   // two column blocks (j, j + 512) per pass: eight loads requested together
+            h16x8 vv[2][4];
+            const int j2 = j + 512 < g.n_kv ? j + 512 : j;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int d = d0 + 16 * r < g.Dv ? d0 + 16 * r : d0;
-                vv[r] = *(const h16x8 *) (pv + (int64_t) d * g.v_nb1 + (int64_t) j * 2);
-                if (FRESH && j + 8 > f.j0 && j < f.j0 + f.N) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if ((unsigned) (j + e - f.j0) < (unsigned) f.N) vv[r][e] = vnew[(j + e - f.j0) * g.Dv + d];
-                }
+                vv[0][r] = *(const h16x8 *) (pv + (int64_t) d * g.v_nb1 + (int64_t) j * 2);
+                vv[1][r] = *(const h16x8 *) (pv + (int64_t) d * g.v_nb1 + (int64_t) j2 * 2);
             }
-            float p[8];
+            float p[2][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) p[e] = sc[j + e];
+            for (int e = 0; e < 8; ++e) { p[0][e] = sc[j + e]; p[1][e] = j + 512 < g.n_kv ? sc[j2 + e] : 0.0f; }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[r] += (float) vv[r][e] * p[e];
+                for (int e = 0; e < 8; ++e) acc[r] += (float) vv[0][r][e] * p[0][e] + (float) vv[1][r][e] * p[1][e];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float t = wave_sum(acc[r]);
-            if (lane == 0 && d0 + 16 * r < g.Dv) out[d0 + 16 * r] = t;
+            float t = wave_sum(acc[r]);
+            const int d = d0 + 16 * r;
+            if (lane == 0 && d < g.Dv) {
+                if (FRESH) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) if (i < f.N) t += pfresh[i] * (float) vnew[i * g.Dv + d];
+                }
+                out[d] = t;
+            }
         }
     }
 }

@@ -38,9 +38,9 @@ def gguf(request, tmp_path_factory):
     return str(path)
 
 
-@pytest.mark.parametrize("fuse", ["1", "0", "attn_rope"])
+@pytest.mark.parametrize("fuse", ["1", "0", "two_launch_attention"])
 def test_logits_match_cpu_backend_matvec_path(gguf, fuse):
-    env = {"GGML_MI355X_ATTN_ROPE": "1"} if fuse == "attn_rope" else {"GGML_MI355X_FUSE": fuse}      # attn_rope: the opt-in single launch
+    env = {"GGML_MI355X_ATTN_ROPE": "0"} if fuse == "two_launch_attention" else {"GGML_MI355X_FUSE": fuse}
     r = run("compare", "--gguf", gguf, "-p", "8", "-n", "8", "-t", "8", env=env)
     print(r)
     assert "MI355X0" in r["devices"]
