@@ -696,6 +696,7 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
     _Float16 * vnew = knew + (FRESH ? f.N * D : 0);
     const float * pm = (const float *) (g.mask + (int64_t) n * g.m_nb1);
     const char *  pk = g.k + (int64_t) hk * g.k_nb2 + (int64_t) l8 * CH * 2;
+    // (measured and dropped: all of a group's K rows and all of a wave's V rows requested up front, 64 + 64 VGPRs: tg128 403 -> 395)
     // two rows (jt, jt + 128) per trip, their loads issued together and one trip ahead of the arithmetic; the first trip is
     // requested before anything else, so with FRESH the cache rows are already on their way while q / k / v are prepared
     auto load_trip = [&](int jt, h16x8 (&kv)[2][NV], float (&mk)[2]) {
