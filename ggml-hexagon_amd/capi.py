@@ -56,7 +56,7 @@ class QmmTensor(C.Structure):
 
 # enum qmm_op
 (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_SCALE, OP_SILU, OP_GELU, OP_GELU_QUICK, OP_RELU, OP_TANH, OP_SIGMOID, OP_NEG, OP_EXP, OP_RMS_NORM,
- OP_ROPE, OP_SOFT_MAX, OP_CPY, OP_GET_ROWS, OP_MUL_MAT_F, OP_RMS_NORM_MUL, OP_SILU_MUL, OP_ARGSORT, OP_SUM_ROWS) = range(1, 24)
+ OP_ROPE, OP_SOFT_MAX, OP_CPY, OP_GET_ROWS, OP_MUL_MAT_F, OP_RMS_NORM_MUL, OP_SILU_MUL, OP_ARGSORT, OP_SUM_ROWS, OP_NORM) = range(1, 25)
 
 
 class QmmWeight(C.Structure):

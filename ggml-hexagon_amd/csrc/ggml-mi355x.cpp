@@ -690,6 +690,7 @@ int glue_op(const ggml_tensor * node) {
         case GGML_OP_DIV:      return QMM_OP_DIV;
         case GGML_OP_SCALE:    return QMM_OP_SCALE;
         case GGML_OP_RMS_NORM: return QMM_OP_RMS_NORM;
+        case GGML_OP_NORM:     return QMM_OP_NORM;
         case GGML_OP_ROPE:     return QMM_OP_ROPE;
         case GGML_OP_SOFT_MAX: return QMM_OP_SOFT_MAX;
         case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: return QMM_OP_CPY;

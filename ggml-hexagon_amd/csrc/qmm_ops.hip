@@ -187,6 +187,25 @@ rms_norm_kernel(const char * __restrict__ x, const float * __restrict__ w, char 
     }
 }
 
+// ggml_compute_forward_norm_f32 (ggml-cpu.c:6183-6232), the LayerNorm of GPT-2 / Falcon / Phi-style models: mean over the row,
+// then the variance of the centred values, y = (x - mean) / sqrt(var + eps).  One block per row, two passes over L2.
+__global__ void __launch_bounds__(256)
+norm_kernel(const char * __restrict__ x, char * __restrict__ y, const Shape sx, const Shape sy, const float eps) {
+    __shared__ float red[4];
+    uint32_t i1, i2, i3;
+    row_coords(blockIdx.x, (uint32_t) sx.ne[1], (uint32_t) sx.ne[2], i1, i2, i3);
+    const float * px = (const float *) (x + i1 * sx.nb[1] + i2 * sx.nb[2] + i3 * sx.nb[3]);
+    float *       py = (float *) (y + i1 * sy.nb[1] + i2 * sy.nb[2] + i3 * sy.nb[3]);
+    const uint32_t n = (uint32_t) sx.ne[0];
+    float sum = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) sum += px[i];
+    const float mean = block_reduce<false>(sum, red) / (float) n;
+    float sum2 = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) { const float v = px[i] - mean; sum2 += v * v; }
+    const float scale = 1.0f / sqrtf(block_reduce<false>(sum2, red) / (float) n + eps);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) py[i] = (px[i] - mean) * scale;
+}
+
 // The same for rows of up to NT*16 floats with 16-byte aligned rows: the row is read once with float4 loads and kept in
 // registers, the norm weight is requested before the reduction so its latency hides behind it.  Few rows (token generation)
 // run with 1024 threads per row, many rows (prefill) with 256.
@@ -1365,6 +1384,7 @@ int qmm_op_supported(int op, const qmm_tensor * a, const qmm_tensor * b, const q
     if (is_unary(op)) return sup_unary(a, d);
     switch (op) {
         case QMM_OP_RMS_NORM:     return sup_rms_norm(a, d);
+        case QMM_OP_NORM:         return sup_rms_norm(a, d);
         case QMM_OP_RMS_NORM_MUL: return sup_rms_norm(a, d) && b && b->type == G_F32 && contiguous(b) && b->ne[0] == a->ne[0] && nelements(b) == b->ne[0];
         case QMM_OP_SILU_MUL:     return sup_unary(a, d) && b && sup_unary(b, d);
         case QMM_OP_ROPE:         return sup_rope(a, b, c, d);
@@ -1408,6 +1428,13 @@ int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * a, const qmm_tensor
         case QMM_OP_NEG:        return launch_unary<QMM_OP_NEG, false>(st, a, nullptr, d, 0);
         case QMM_OP_EXP:        return launch_unary<QMM_OP_EXP, false>(st, a, nullptr, d, 0);
         case QMM_OP_SILU_MUL:   return launch_unary<QMM_OP_SILU, true>(st, a, b, d, 0);
+        case QMM_OP_NORM: {
+            const float eps = f32_param(d, 0);
+            if (eps < 0.0f) return fail(QMM_EINVAL, "NORM: eps < 0");
+            hipLaunchKernelGGL(norm_kernel, dim3((unsigned) nrows(d)), dim3(256), 0, st, (const char *) a->data, (char *) d->data, shape_of(a), shape_of(d), eps);
+            HIP_TRY(hipGetLastError());
+            return QMM_OK;
+        }
         case QMM_OP_RMS_NORM:
         case QMM_OP_RMS_NORM_MUL:
             return launch_rms_norm(st, a, nullptr, op == QMM_OP_RMS_NORM_MUL ? b : nullptr, d, nullptr, f32_param(d, 0));

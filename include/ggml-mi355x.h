@@ -10,7 +10,7 @@
  * src1/dst F32 — the quantized mulmat the reference's cDSP path gates in
  * ggmlhexagon_can_handle_op_through_cdsp (ggml-hexagon.cpp:5065-5115) — plus, so that a transformer layer is one scheduler
  * split and the KV cache lives in HBM, the ops around it (include/ggml_mi355x_ops.h): ADD SUB MUL DIV SCALE,
- * SILU GELU RELU TANH SIGMOID NEG EXP, RMS_NORM, ROPE, SOFT_MAX, CPY CONT DUP, GET_ROWS, ARGSORT, SUM_ROWS and MUL_MAT with an
+ * SILU GELU RELU TANH SIGMOID NEG EXP, NORM, RMS_NORM, ROPE, SOFT_MAX, CPY CONT DUP, GET_ROWS, ARGSORT, SUM_ROWS and MUL_MAT with an
  * F16 / F32 src0.  GGML_MI355X_GLUE=0 restricts the device to the two quantized ops.
  */
 #pragma once

@@ -47,6 +47,7 @@ enum qmm_op {
     /* the MoE router (build_moe_ffn) */
     QMM_OP_ARGSORT,           /* i32 indices that order each row; op_params[0] = 0 ascending, 1 descending (ggml_top_k = this + a view) */
     QMM_OP_SUM_ROWS,          /* dst [1, ne1, ne2, ne3] = row sums */
+    QMM_OP_NORM,              /* LayerNorm without affine part: (x - mean) / sqrt(var + eps), op_params[0] = eps */
     QMM_OP_COUNT
 };
 

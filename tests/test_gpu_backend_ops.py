@@ -43,7 +43,7 @@ def test_reference_harness_passes(op, min_ok):
 
 
 # the glue ops of a layer; default tolerance of the harness: NMSE <= 1e-7 (tests/test-backend-ops.cpp:325-327)
-@pytest.mark.parametrize("op,min_ok", [("ADD", 20), ("MUL", 20), ("DIV", 20), ("SCALE", 1), ("SILU", 1), ("RMS_NORM", 6), ("ROPE", 60),
+@pytest.mark.parametrize("op,min_ok", [("ADD", 20), ("MUL", 20), ("DIV", 20), ("SCALE", 1), ("SILU", 1), ("RMS_NORM", 6), ("NORM", 6), ("ARGSORT", 4), ("SUM_ROWS", 1), ("ROPE", 60),
                                        ("SOFT_MAX", 60), ("CPY", 20), ("CONT", 4), ("GET_ROWS", 20)])
 def test_reference_harness_passes_glue_ops(op, min_ok):
     rc, out = run_tbo("test", "-o", op)
