@@ -454,14 +454,36 @@ struct RopeStoreArgs {
     RopeParams rp;
     uint32_t nq, nk, nv;          // pairs of q, pairs of k, elements of v
 };
+// VT: the v part is a 2-D transpose (v_cur^T, dense along its dim 1, into rows of the transposed cache, dense along dim 0) and
+// large enough for 32 x 32 tiles through LDS: blocks behind the rope blocks take one tile each, reading along the source's dense
+// direction and writing along the destination's (the element-wise form reads 4-byte values 4 KB apart)
+template <bool VT>
 __global__ void __launch_bounds__(256)
-rope_store_kernel(const RopeStoreArgs g) {
+rope_store_kernel(const RopeStoreArgs g, const uint32_t pair_blocks, const uint32_t tiles0) {
+    if (VT && blockIdx.x >= pair_blocks) {
+        __shared__ float tile[32][33];
+        const uint32_t t = blockIdx.x - pair_blocks, b0 = (t % tiles0) * 32, b1 = (t / tiles0) * 32;
+        const uint32_t ne0 = (uint32_t) g.sv.ne[0], ne1 = (uint32_t) g.sv.ne[1];
+        const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i0 = b0 + ty + j * 8, i1 = b1 + tx;
+            if (i0 < ne0 && i1 < ne1) tile[ty + j * 8][tx] = *(const float *) (g.v + (size_t) i0 * g.sv.nb[0] + (size_t) i1 * 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i0 = b0 + tx, i1 = b1 + ty + j * 8;
+            if (i0 < ne0 && i1 < ne1) *(__half *) (g.vd + (size_t) i0 * 2 + (size_t) i1 * g.svd.nb[1]) = __float2half(tile[tx][ty + j * 8]);
+        }
+        return;
+    }
     uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (gid < g.nq) { rope_pair<float>(g.q, g.pos, g.ff, g.qd, g.sq, g.sqd, g.rp, gid); return; }
     gid -= g.nq;
     if (gid < g.nk) { rope_pair<__half>(g.k, g.pos, g.ff, g.kd, g.sk, g.skd, g.rp, gid); return; }
     gid -= g.nk;
-    if (gid < g.nv) st_from_f32<__half>(g.vd + elem_offset(gid, g.svd), ld_as_f32<float>(g.v + elem_offset(gid, g.sv)));
+    if (!VT && gid < g.nv) st_from_f32<__half>(g.vd + elem_offset(gid, g.svd), ld_as_f32<float>(g.v + elem_offset(gid, g.sv)));
 }
 
 // ------------------------------------------------------------------------------------------------ GET_ROWS
@@ -1594,8 +1616,15 @@ int qmm_rope_kv_store(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * po
     g.pos = (const int32_t *) pos->data; g.ff = ff ? (const float *) ff->data : nullptr;
     g.rp = rope_params(q_dst);
     g.nq = (uint32_t) (nelements(q) / 2); g.nk = k ? (uint32_t) (nelements(k) / 2) : 0; g.nv = v ? (uint32_t) nelements(v) : 0;
-    const uint32_t total = g.nq + g.nk + g.nv;
-    hipLaunchKernelGGL(rope_store_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->s(stream), g);
+    const bool vt = v && v->ne[2] == 1 && v->ne[3] == 1 && v_dst->ne[2] == 1 && v_dst->ne[3] == 1 && v->ne[0] == v_dst->ne[0] && v->ne[1] == v_dst->ne[1] &&
+                    v->nb[1] == 4 && v_dst->nb[0] == 2 && v->ne[0] >= 32 && v->ne[1] >= 32;
+    if (vt) {
+        const uint32_t pair_blocks = (g.nq + g.nk + 255) / 256, tiles0 = (uint32_t) ((v->ne[0] + 31) / 32), tiles1 = (uint32_t) ((v->ne[1] + 31) / 32);
+        hipLaunchKernelGGL((rope_store_kernel<true>), dim3(pair_blocks + tiles0 * tiles1), dim3(256), 0, ctx->s(stream), g, pair_blocks, tiles0);
+    } else {
+        const uint32_t total = g.nq + g.nk + g.nv;
+        hipLaunchKernelGGL((rope_store_kernel<false>), dim3((total + 255) / 256), dim3(256), 0, ctx->s(stream), g, 0u, 0u);
+    }
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }

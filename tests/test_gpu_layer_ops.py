@@ -152,7 +152,7 @@ def rope_ref(x, pos, n_dims, theta_scale):
     return out
 
 
-@pytest.mark.parametrize("n_tok", [1, 5])
+@pytest.mark.parametrize("n_tok", [1, 5, 70])
 def test_rope_kv_store_one_launch(qmm, n_tok):
     """rope(q) -> f32, rope(k) -> f16 K cache rows, v -> transposed f16 V cache, as build_attn lays them out"""
     from ggml_hexagon_amd import capi
