@@ -51,14 +51,13 @@ bool aligned_to(const qmm_tensor * t, int a) {
     return (uintptr_t) t->data % a == 0 && t->nb[1] % a == 0 && t->nb[2] % a == 0 && t->nb[3] % a == 0;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// wave_sum / wave_max: the DPP reductions of qmm_device.cuh (no LDS-permute traffic; the __shfl_xor butterflies this file began
+// with cost ~0.3 us per reduction: 16 us of the 37 us of attn_prefill_kernel's last token tile were its per-row soft-max)
+// sum over an aligned group of 8 lanes, result in all 8
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_mov<DPP_QUAD_X1>(v);
+    v += dpp_mov<DPP_QUAD_X2>(v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
     return v;
 }
 // block-wide reductions (up to 16 waves) through 16 floats of LDS
@@ -813,9 +812,7 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
             for (int c = 0; c < NV; ++c)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += (float) kv[r][c][e] * qf[c * 8 + e];
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
+            s = sum8(s);
             s = s * g.scale + mk[r];
             if (j < g.n_kv) {
                 if (l8 == 0) sc[j] = s;
@@ -930,9 +927,7 @@ attn_decode_split_kernel(const AttnArgs g, float * __restrict__ part, const int 
             for (int c = 0; c < NV; ++c)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += (float) kv[r][c][e] * qf[c * 8 + e];
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
+            s = sum8(s);
             s = s * g.scale + mk[r];
             if (j < j_hi) {
                 if (l8 == 0) sc[j - j_lo] = s;
