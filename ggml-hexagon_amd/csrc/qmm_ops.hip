@@ -1091,39 +1091,56 @@ attn_prefill_kernel(const AttnArgs g, const int N) {
         if (live_tiles == 0) continue;                                     // block-uniform: the whole chunk is masked for these tokens
         // 2. soft_max step: 16 rows per wave, <= 512 values = two float4 per lane; running max / sum per row
         const int cw = c1 - c0;
-        for (int nl = wave * 16; nl < wave * 16 + 16; ++nl) {
-            float * row = S + nl * SP;
-            float4 v[2];
-            float mx = -INFINITY;
+        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+        for (int n4 = wave * 16; n4 < wave * 16 + 16; n4 += 4) {            // four rows at a time: their reads, reductions and exps interleave
+            float4 v[4][2];
+            float mx[4], m_old[4], m_new[4], sum[4], alpha[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int i = 4 * (lane + 64 * t);
-                v[t] = i < cw ? *(const float4 *) (row + i) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                mx = fmaxf(fmaxf(mx, fmaxf(v[t].x, v[t].y)), fmaxf(v[t].z, v[t].w));
+            for (int q = 0; q < 4; ++q) {
+                const float * row = S + (n4 + q) * SP;
+                mx[q] = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int i = 4 * (lane + 64 * t);
+                    v[q][t] = i < cw ? *(const float4 *) (row + i) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                    mx[q] = fmaxf(fmaxf(mx[q], fmaxf(v[q][t].x, v[q][t].y)), fmaxf(v[q][t].z, v[q][t].w));
+                }
+                m_old[q] = row_max[n4 + q];
             }
-            const float m_old = row_max[nl], m_new = fmaxf(m_old, wave_max(mx));
-            float sum = 0.0f;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (m_new == -INFINITY) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                else { v[t].x = expf(v[t].x - m_new); v[t].y = expf(v[t].y - m_new); v[t].z = expf(v[t].z - m_new); v[t].w = expf(v[t].w - m_new); }
-                sum += v[t].x + v[t].y + v[t].z + v[t].w;
+            for (int q = 0; q < 4; ++q) m_new[q] = fmaxf(m_old[q], wave_max(mx[q]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sum[q] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float4 & x = v[q][t];
+                    if (m_new[q] == -INFINITY) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else { x.x = __expf(x.x - m_new[q]); x.y = __expf(x.y - m_new[q]); x.z = __expf(x.z - m_new[q]); x.w = __expf(x.w - m_new[q]); }
+                    sum[q] += x.x + x.y + x.z + x.w;
+                }
             }
-            sum = wave_sum(sum);
-            const float alpha = m_old == -INFINITY ? 0.0f : expf(m_old - m_new);
-            if (single) {                                                  // one chunk: normalise before the f16 rounding, exactly as the CPU path does
-                const float inv = 1.0f / sum;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) { v[t].x *= inv; v[t].y *= inv; v[t].z *= inv; v[t].w *= inv; }
-                sum = 1.0f;
+            for (int q = 0; q < 4; ++q) {
+                sum[q] = wave_sum(sum[q]);
+                alpha[q] = m_old[q] == -INFINITY ? 0.0f : __expf(m_old[q] - m_new[q]);
             }
-            if (lane == 0) { row_max[nl] = m_new; row_sum[nl] = row_sum[nl] * alpha + sum; row_alpha[nl] = alpha; }
-            _Float16 * prow = reinterpret_cast<_Float16 *>(row);           // p as f16 over the first half of the row's own bytes
-            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int i = 4 * (lane + 64 * t);
-                if (i < cw) *(h16x4 *) (prow + i) = h16x4{ (_Float16) v[t].x, (_Float16) v[t].y, (_Float16) v[t].z, (_Float16) v[t].w };
+            for (int q = 0; q < 4; ++q) {
+                if (single) {                                              // one chunk: normalise before the f16 rounding, exactly as the CPU path does
+                    const float inv = 1.0f / sum[q];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) { v[q][t].x *= inv; v[q][t].y *= inv; v[q][t].z *= inv; v[q][t].w *= inv; }
+                    sum[q] = 1.0f;
+                }
+                const int nl = n4 + q;
+                if (lane == 0) { row_max[nl] = m_new[q]; row_sum[nl] = row_sum[nl] * alpha[q] + sum[q]; row_alpha[nl] = alpha[q]; }
+                _Float16 * prow = reinterpret_cast<_Float16 *>(S + nl * SP);    // p as f16 over the first half of the row's own bytes
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int i = 4 * (lane + 64 * t);
+                    if (i < cw) *(h16x4 *) (prow + i) = h16x4{ (_Float16) v[q][t].x, (_Float16) v[q][t].y, (_Float16) v[q][t].z, (_Float16) v[q][t].w };
+                }
             }
         }
         __syncthreads();                                                   // tile_dead, row_alpha and the p rows are visible to everyone
