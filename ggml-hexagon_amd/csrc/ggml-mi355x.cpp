@@ -841,7 +841,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
             const ggml_tensor * n0 = cgraph->nodes[i];
             if (n0->op == GGML_OP_RMS_NORM || (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU) ||
                 n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT || n0->op == GGML_OP_ROPE || n0->op == GGML_OP_MUL ||
-                n0->op == GGML_OP_GET_ROWS || n0->op == GGML_OP_SUM_ROWS)
+                n0->op == GGML_OP_GET_ROWS || n0->op == GGML_OP_SUM_ROWS || n0->op == GGML_OP_ADD)
                 rd.push_back({ n0, 0, -1, true });
         }
         if (!rd.empty()) {
@@ -999,6 +999,42 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                             done[jc] = 1;
                             continue;
                         }
+                    }
+                }
+            }
+            if (node->op == GGML_OP_MUL && node->src[1]->ne[0] == 1 && node->ne[1] >= 2 && node->ne[1] == node->src[1]->ne[1] && node->ne[3] == 1 &&
+                !GGML_MI355X_FUSE_OFF()) {
+                // experts * weights and the sum over the used experts through 2-D views (build_moe_ffn's tail): one launch
+                const int U = (int) node->ne[1];
+                const auto * rm = info(node);
+                int idx[64], k = 0;
+                for (int j = i + 1; j < n_nodes && j <= i + 4 * U + 4 && k < U - 1; ++j) {
+                    const ggml_tensor * t = cgraph->nodes[j];
+                    if (done[j] || is_noop(t)) continue;
+                    if (t->op != GGML_OP_ADD) break;
+                    idx[k++] = j;
+                }
+                const auto root = [](const ggml_tensor * t) { return t->view_src ? t->view_src : t; };
+                const auto is_slice = [&](const ggml_tensor * v, int u) {           // view_2d(experts, E, N, nb[2], u * nb[1])
+                    return root(v) == node && v->ne[0] == node->ne[0] && v->ne[1] == node->ne[2] && v->ne[2] == 1 && v->nb[1] == node->nb[2] &&
+                           (const char *) v->data == (const char *) node->data + (size_t) u * node->nb[1];
+                };
+                bool ok = k == U - 1 && rm && rm->uses == U && U <= 64 && !(node->flags & GGML_TENSOR_FLAG_OUTPUT);
+                for (int a = 0; ok && a < U - 1; ++a) {
+                    const ggml_tensor * ad = cgraph->nodes[idx[a]];
+                    ok = is_slice(ad->src[1], a + 1) && (a == 0 ? is_slice(ad->src[0], 0) : ad->src[0] == cgraph->nodes[idx[a - 1]]) &&
+                         (a == U - 2 || (single_use(ad) && !(ad->flags & GGML_TENSOR_FLAG_OUTPUT)));
+                }
+                if (ok) {
+                    const ggml_tensor * last = cgraph->nodes[idx[U - 2]];
+                    const qmm_tensor x = to_qt(node->src[0], ctx), w = to_qt(node->src[1], ctx), o = to_qt(last, ctx);
+                    if (qmm_moe_combine_supported(&x, &w, &o)) {
+                        if (qmm_moe_combine(ctx->dev->qmm, &x, &w, &o, qmm_stream(ctx->dev->qmm))) {
+                            GGML_LOG_ERROR("MI355X MoE combine(%s): %s\n", node->name, qmm_last_error());
+                            return GGML_STATUS_FAILED;
+                        }
+                        for (int a = 0; a < U - 1; ++a) done[idx[a]] = 1;
+                        continue;
                     }
                 }
             }

@@ -655,6 +655,29 @@ moe_router_kernel(const char * __restrict__ logits, char * __restrict__ ids, cha
     if (sel) ((float *) (weights + (int64_t) t * w_nb1))[rank] = normalise ? p / sum : p;
 }
 
+// The other end of a mixture-of-experts block (build_moe_ffn, src/llama-graph.cpp:896-911): experts * weights, then the sum over the
+// used experts through 2-D views, as one launch: out[n][c] = ((x[n][0][c] w[n][0] + x[n][1][c] w[n][1]) + ...), in the graph's order.
+__global__ void __launch_bounds__(256)
+moe_combine_kernel(const char * __restrict__ x, const char * __restrict__ w, char * __restrict__ out, const int64_t x_nb1, const int64_t x_nb2,
+                   const int64_t w_nb1, const int64_t w_nb2, const int64_t o_nb1, const int E, const int U) {
+    const int n = blockIdx.y;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= E) return;
+    const char * px = x + (int64_t) n * x_nb2 + (int64_t) c * 4;
+    const char * pw = w + (int64_t) n * w_nb2;
+    float4 acc = *(const float4 *) px;
+    {
+        const float w0 = *(const float *) pw;
+        acc.x *= w0; acc.y *= w0; acc.z *= w0; acc.w *= w0;
+    }
+    for (int u = 1; u < U; ++u) {
+        const float4 v = *(const float4 *) (px + (int64_t) u * x_nb1);
+        const float wu = *(const float *) (pw + (int64_t) u * w_nb1);
+        acc.x += v.x * wu; acc.y += v.y * wu; acc.z += v.z * wu; acc.w += v.w * wu;
+    }
+    *(float4 *) (out + (int64_t) n * o_nb1 + (int64_t) c * 4) = acc;
+}
+
 // Few outputs with a long K (the MoE router at batch 1: 8 x 4096): one WORKGROUP per dst element, so K is spread over 256 threads
 // instead of 64 (the wave-per-element kernel walks K = 4096 in 64 dependent trips: 27 us per call, 0.87 ms per Mixtral token).
 __global__ void __launch_bounds__(256)
@@ -1757,6 +1780,26 @@ int qmm_moe_router(qmm_ctx * ctx, const qmm_tensor * logits, const qmm_tensor * 
     const int N = (int) logits->ne[1];
     hipLaunchKernelGGL(moe_router_kernel, dim3((N + 3) / 4), dim3(256), 0, ctx->s(stream), (const char *) logits->data, (char *) ids->data,
                        (char *) weights->data, logits->nb[1], ids->nb[1], (int64_t) n_used * 4, (int) logits->ne[0], (int) n_used, N, normalise);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+int qmm_moe_combine_supported(const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * out) {
+    if (!x || !w || !out || x->type != G_F32 || w->type != G_F32 || out->type != G_F32) return 0;
+    const int64_t E = x->ne[0], U = x->ne[1], N = x->ne[2];
+    if (E < 4 || E % 4 || U < 1 || U > 64 || N < 1 || N > 65535 || x->ne[3] != 1) return 0;
+    if (w->ne[0] != 1 || w->ne[1] != U || w->ne[2] != N || w->ne[3] != 1 || out->ne[0] != E || out->ne[1] != N || out->ne[2] != 1 || out->ne[3] != 1) return 0;
+    if (x->nb[0] != 4 || out->nb[0] != 4 || x->nb[1] % 16 || x->nb[2] % 16 || out->nb[1] % 16 || w->nb[1] % 4 || w->nb[2] % 4) return 0;
+    return 1;
+}
+
+int qmm_moe_combine(qmm_ctx * ctx, const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * out, void * stream) {
+    if (!ctx || !qmm_moe_combine_supported(x, w, out)) return fail(QMM_EUNSUPPORTED, "qmm_moe_combine: operands not supported");
+    if ((uintptr_t) x->data % 16 || (uintptr_t) out->data % 16) return fail(QMM_EINVAL, "qmm_moe_combine: x / out must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int E = (int) x->ne[0];
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned) ((E / 4 + 255) / 256), (unsigned) x->ne[2]), dim3(256), 0, ctx->s(stream), (const char *) x->data,
+                       (const char *) w->data, (char *) out->data, x->nb[1], x->nb[2], w->nb[1], w->nb[2], out->nb[1], E, (int) x->ne[1]);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }

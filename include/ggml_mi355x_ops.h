@@ -104,6 +104,11 @@ QMM_API int qmm_moe_router_supported(const qmm_tensor * logits, const qmm_tensor
 QMM_API int qmm_moe_router(qmm_ctx * ctx, const qmm_tensor * logits, const qmm_tensor * ids, const qmm_tensor * weights, int64_t n_used,
                            int normalise, void * stream);
 
+/* The other end of the block: out [E, n_tokens] = sum over the used experts of x [E, n_used, n_tokens] * w [1, n_used, n_tokens]
+ * (ggml_mul by the router weights, then the ggml_add chain over 2-D views, src/llama-graph.cpp:896-911), in the graph's order. */
+QMM_API int qmm_moe_combine_supported(const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * out);
+QMM_API int qmm_moe_combine(qmm_ctx * ctx, const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * out, void * stream);
+
 /* qmm_rope_kv_store and qmm_attn_decode as ONE launch for a batch of up to 8 tokens (normal-mode RoPE over the whole head,
  * D <= 128): q [D, H, N] arrives un-roped (q_rope: the ROPE node's descriptor, for its op_params), k_new [D, H_kv, N] and
  * v_new (v_cur^T, [N, Dv * H_kv]) are the batch's projections, k_store / v_store where qmm_rope_kv_store would put them, k / v the

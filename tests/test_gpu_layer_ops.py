@@ -344,3 +344,25 @@ def test_moe_router_one_launch(qmm, n_tok, n_expert, n_used):
     assert np.array_equal(ids.cpu().numpy(), order.astype(np.int32))
     sel = np.take_along_axis(p, order[:, :n_used], axis=1)
     assert np.allclose(w.cpu().numpy(), sel / sel.sum(axis=1, keepdims=True), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_tok,n_used,e", [(1, 2, 4096), (70, 2, 1024), (5, 6, 512)])
+def test_moe_combine_one_launch(qmm, n_tok, n_used, e):
+    """experts * weights and the sum over the used experts (build_moe_ffn's tail) in one launch, in place over slice 0 as ggml-alloc
+    lays it out, against numpy in the graph's order of operations"""
+    from ggml_hexagon_amd import capi
+    rng = np.random.default_rng(n_tok + e)
+    x = rng.normal(0, 1, (n_tok, n_used, e)).astype(np.float32)
+    w = rng.uniform(0.1, 0.9, (n_tok, n_used, 1)).astype(np.float32)
+    dx, dw = dev(x), dev(w)
+    M = capi.QmmTensor.make
+    r = lambda t: capi.C.byref(t)
+    tx = M(F32, [e, n_used, n_tok], data=dx.data_ptr())
+    tw = M(F32, [1, n_used, n_tok], data=dw.data_ptr())
+    to = M(F32, [e, n_tok], nb=[4, n_used * e * 4, n_used * e * 4 * n_tok, n_used * e * 4 * n_tok], data=dx.data_ptr())   # view_2d of slice 0
+    qmm._chk(qmm.lib.qmm_moe_combine(qmm.ctx, r(tx), r(tw), r(to), qmm._stream()))
+    want = x[:, 0] * w[:, 0]
+    for u in range(1, n_used):
+        want = want + x[:, u] * w[:, u]
+    got = dx.cpu().numpy()[:, 0]
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
