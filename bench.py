@@ -93,6 +93,33 @@ def roofline_leg(hp, q, n_batch, torch, n_outputs=None):
     return agg
 
 
+def llama_bench_cpu(name, threads=16):
+    """Part of the cpu_baseline leg: the reference's own libllama (oracle/_ref, unmodified) on its CPU backend, llama-bench's
+    protocol through tests/cpp/llama_e2e.cpp, on a bounded sample (one pp512 after the warm-up, 16 generated tokens): the whole
+    model end to end (attention, norms, sampling-free decode), not only its MUL_MATs.  None when the binary is not there."""
+    import json as _json
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "llama-e2e")
+    if not os.path.exists(exe) or name.startswith(("mixtral", "llama3-70b")) or shutil.disk_usage(tempfile.gettempdir()).free < (12 << 30):
+        return None
+    tmp = tempfile.mkdtemp(prefix="qmm_bench_")
+    try:
+        gguf = os.path.join(tmp, "m.gguf")
+        env = {k: v for k, v in os.environ.items() if k != "GGML_BACKEND_PATH"}          # CPU backend only
+        subprocess.run([exe, "write", "--config", name, "--gguf", gguf], check=True, capture_output=True, timeout=120, env=env)
+        p = subprocess.run([exe, "bench", "--gguf", gguf, "--ngl", "0", "-p", "512", "-n", "16", "-r", "1", "-t", str(threads)],
+                           check=True, capture_output=True, text=True, timeout=240, env=env)
+        r = _json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        return {"pp512_tok_s": r["pp_tok_s"], "tg_tok_s": r["tg_tok_s"], "threads": threads, "kind": "reference",
+                "sample": "llama_model_load + llama_decode of the reference's libllama on the ggml CPU backend: warm-up, one pp512, 16 generated tokens"}
+    except Exception as e:              # reported-only
+        return {"pp512_tok_s": None, "tg_tok_s": None, "threads": threads, "kind": "reference", "sample": f"failed: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(wl, cores):
     """the reference's CPU backend (oracle/_ref, built from /root/reference) or, failing that, our C port, timed on
     this host on a bounded sample: the MUL_MATs of one 'more-bits' and one ordinary layer + the output projection
@@ -139,7 +166,9 @@ def cpu_baseline(wl, cores):
             t_pp += dp * (M / Mp) * count
         else:
             t_pp = float("nan")
+    e2e = llama_bench_cpu(wl.name)
     return {"value": round(1.0 / t_tg, 3), "unit": "tok/s (tg128)", "pp512_tok_s": None if t_pp != t_pp else round(512.0 / t_pp, 2),
+            "llama_bench_protocol": e2e,
             "cores": cores, "kind": kind, "variant": getattr(ref, "variant", "scalar+omp"),
             "sample": f"each distinct (type,K,M) of {wl.name} once at N=1 (x3) and N=512 (rows capped at 16384/4096, scaled), "
                       f"summed over the model's {len(mats)} MUL_MATs ({per_layer} per layer); prompt pass as llama-bench runs it: "
