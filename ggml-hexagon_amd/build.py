@@ -25,14 +25,13 @@ def _newer(target: Path, sources) -> bool:
 def build_qmm(force: bool = False) -> Path:
     """the kernel library behind include/ggml_mi355x_qmm.h and include/ggml_mi355x_ops.h: one object per translation unit
     (qmm_api.hip = the quantized MUL_MAT path, qmm_ops.hip = the glue ops), rebuilt only when its sources changed"""
-    headers = sorted(CSRC.glob("qmm_*.cuh")) + sorted(CSRC.glob("qmm_*.h")) + sorted((ROOT / "include").glob("ggml_mi355x_*.h"))
+    headers = sorted(CSRC.glob("qmm_*.hiph")) + sorted(CSRC.glob("qmm_*.h")) + sorted((ROOT / "include").glob("ggml_mi355x_*.h"))
     units = [CSRC / "qmm_api.hip", CSRC / "qmm_ops.hip"]
     if not force and _newer(QMM_SO, units + headers):
         return QMM_SO
     if not shutil.which(HIPCC):
-        if QMM_SO.exists():
-            return QMM_SO
-        raise RuntimeError("hipcc not found and no prebuilt libggml_mi355x_qmm.so")
+        # a library older than its sources is never used silently: a stale kernel must not be tested or benchmarked
+        raise RuntimeError("hipcc not found and libggml_mi355x_qmm.so is " + ("older than its sources" if QMM_SO.exists() else "missing"))
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-slp-vectorize"]
     objs, jobs = [], []
     for u in units:

@@ -3,10 +3,10 @@
 
 #include "qmm_host.h"
 
-#include "qmm_matvec.cuh"
-#include "qmm_mfma.cuh"
-#include "qmm_mfma_regb.cuh"
-#include "qmm_moe.cuh"
+#include "qmm_matvec.hiph"
+#include "qmm_mfma.hiph"
+#include "qmm_mfma_regb.hiph"
+#include "qmm_moe.hiph"
 
 using namespace qmm;
 

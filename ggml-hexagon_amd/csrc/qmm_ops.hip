@@ -5,7 +5,7 @@
 
 #include "qmm_host.h"
 #include "../../include/ggml_mi355x_ops.h"
-#include "qmm_device.cuh"
+#include "qmm_device.hiph"
 
 #include <hip/hip_fp16.h>
 #include <cmath>
@@ -51,7 +51,7 @@ bool aligned_to(const qmm_tensor * t, int a) {
     return (uintptr_t) t->data % a == 0 && t->nb[1] % a == 0 && t->nb[2] % a == 0 && t->nb[3] % a == 0;
 }
 
-// wave_sum / wave_max: the DPP reductions of qmm_device.cuh (no LDS-permute traffic; the __shfl_xor butterflies this file began
+// wave_sum / wave_max: the DPP reductions of qmm_device.hiph (no LDS-permute traffic; the __shfl_xor butterflies this file began
 // with cost ~0.3 us per reduction: 16 us of the 37 us of attn_prefill_kernel's last token tile were its per-row soft-max)
 // sum over an aligned group of 8 lanes, result in all 8
 __device__ __forceinline__ float sum8(float v) {
@@ -498,7 +498,7 @@ get_rows_kernel(const char * __restrict__ x, const char * __restrict__ ids, char
     float *      py = (float *) (y + i10 * sy.nb[1] + i11 * sy.nb[2] + i12 * sy.nb[3]);
     for (uint32_t i = threadIdx.x; i < (uint32_t) sx.ne[0]; i += 256) py[i] = ld_as_f32<TS>(px + (size_t) i * sizeof(TS));
 }
-// quantized rows: one unit per thread, the bit-exact unpack of qmm_device.cuh
+// quantized rows: one unit per thread, the bit-exact unpack of qmm_device.hiph
 template <int T>
 __global__ void __launch_bounds__(256)
 get_rows_q_kernel(const uint8_t * __restrict__ x, const char * __restrict__ ids, char * __restrict__ y, const Shape sx, const Shape si, const Shape sy) {
