@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--n-gen", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--chain", action="store_true", help="token generation as persistent chains (csrc/qmm_chain.hiph) instead of one launch per MUL_MAT group")
     ap.add_argument("--all-logits", action="store_true",
                     help="prompt pass with logits for every token (n_outputs = n_prompt) instead of llama-bench's last-token-only")
     args = ap.parse_args()
@@ -224,6 +225,7 @@ def main():
     wl = workload.get(args.workload)
     concat = RowConcat() if world > 1 else None
     hp = HotPath(q, wl, dev, rank, world, concat)
+    hp.chain = args.chain
     hp.prepare(args.n_prompt)
     hp.prepare(1)
     # llama-bench's prompt test wants the last token's logits only (llama_batch_get_one: batch.logits = NULL ->

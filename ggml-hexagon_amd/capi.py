@@ -19,6 +19,7 @@ EXPORTS = [
     "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_memcpy_h2d_async",
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_dequantize",
     "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_swiglu_in", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
+    "qmm_chain_begin", "qmm_chain_flush", "qmm_chain_end", "qmm_chain_stats", "qmm_chain_debug",
 ]
 # include/ggml_mi355x_ops.h: the glue ops of a transformer layer
 OPS_EXPORTS = [
@@ -118,6 +119,10 @@ def load_library() -> C.CDLL:
     lib.qmm_attn_decode_rope.argtypes = [v, P, P, P, P, P, P, P, P, P, P, P, P, C.c_float, i64, v]
     lib.qmm_mul_mat_id.argtypes = [v, i32, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, i64, i64, v]
     lib.qmm_mul_mat_id_pair.argtypes = [v, i32, v, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, v, i64, i64, v]
+    for f in (lib.qmm_chain_begin, lib.qmm_chain_flush, lib.qmm_chain_end):
+        f.argtypes = [v]
+    lib.qmm_chain_stats.argtypes = [v, C.POINTER(i32), C.POINTER(i32)]
+    lib.qmm_chain_debug.argtypes = [v, v]
     return lib
 
 
@@ -162,6 +167,25 @@ class Qmm:
 
     def row_size(self, t, k):
         return self.lib.qmm_row_size(t, k)
+
+    # --- chains: one-token mul_mat_group[_ex] calls between begin and end are recorded and go out as persistent launches
+    def chain_begin(self):
+        self._chk(self.lib.qmm_chain_begin(self.ctx))
+
+    def chain_flush(self):
+        self._chk(self.lib.qmm_chain_flush(self.ctx))
+
+    def chain_end(self):
+        self._chk(self.lib.qmm_chain_end(self.ctx))
+
+    def chain_debug(self, stamps=None):
+        """stamps: int64 CUDA tensor [steps, cus, 8] (or None to switch off)"""
+        self._chk(self.lib.qmm_chain_debug(self.ctx, stamps.data_ptr() if stamps is not None else None))
+
+    def chain_stats(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.qmm_chain_stats(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     # --- torch-tensor conveniences (uint8 weight tensors [M, row_bytes] on the GPU) ---------------
     def dequantize(self, t, w, k):

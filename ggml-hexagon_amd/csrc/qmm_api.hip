@@ -7,6 +7,7 @@
 #include "qmm_mfma.hiph"
 #include "qmm_mfma_regb.hiph"
 #include "qmm_moe.hiph"
+#include "qmm_chain.hiph"
 
 using namespace qmm;
 
@@ -119,9 +120,125 @@ static int check_mm(int type, const void * w, int64_t rb, int64_t K, const float
     return QMM_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------- chains (qmm_chain.hiph)
+
+static size_t chain_act_bytes(int fam, int ntok, int K) {
+    return fam == CHAIN_FAM_Q8_K ? kmix_lds_bytes(ntok, K) : (((size_t) ntok * K + (size_t) ntok * (K / 32) * 4 + 15) & ~(size_t) 15);
+}
+static size_t chain_step_lds(const ChainStep & st, int ntok) {
+    return chain_act_bytes(st.fam, ntok, st.K) + (st.g.norm_w ? (size_t) ntok * st.K * 4 : 0);
+}
+constexpr size_t CHAIN_SLAB = (size_t) CHAIN_RPW * CHAIN_NW * 4;          // one token
+
+// the step as a launch of its own (a chain of one, or chains switched off): the kernels of round 1
+static int chain_step_plain(qmm_ctx * c, hipStream_t st, const ChainStep & s) {
+    bool uniform = true;
+    for (int i = 1; i < s.g.n; ++i) uniform = uniform && s.g.type[i] == s.g.type[0];
+    if (uniform) return matvec_any(c, st, s.g.type[0], s.g, s.x, s.ldx, s.K, 1);
+    return launch_kmix(c, st, s.g, s.x, s.ldx, s.K, 1);
+}
+
+static int chain_launch(qmm_ctx * c) {
+    if (!c->chain || c->chain->empty()) return QMM_OK;
+    std::vector<ChainStep> & v = *c->chain;
+    hipStream_t st = c->chain_stream;
+    int rc = QMM_OK;
+    for (size_t i = 0; i < v.size() && rc == QMM_OK;) {
+        size_t n = v.size() - i;
+        if (n > (size_t) CHAIN_MAX_STEPS) n = CHAIN_MAX_STEPS;
+        if (n == 1) {
+            rc = chain_step_plain(c, st, v[i]);
+        } else {
+            ChainArgs a;
+            memset(&a, 0, sizeof(a));
+            size_t lds = 0;
+            for (size_t k = 0; k < n; ++k) {
+                a.s[k] = v[i + k];
+                const size_t b = chain_step_lds(a.s[k], 1);
+                if (b > lds) lds = b;
+            }
+            a.sync = c->chain_sync;
+            a.n = (int) n;
+            a.act_mode = c->act_mode;
+            a.timeout = 2000000u;                                           // 20 ms of the 100 MHz clock
+            a.res_off = (uint32_t) ((lds + 15) & ~(size_t) 15);
+            if (c->chain_dbg) {                                             // diagnostic stamps, consecutive launches behind each other
+                a.dbg = c->chain_dbg;
+                c->chain_dbg += n * (size_t) c->cus * 8;
+            }
+            const size_t total = a.res_off + CHAIN_SLAB;
+            auto kern = matvec_chain_kernel<1>;
+            if (!c->chain_attr_set) {
+                hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+                if (e != hipSuccess) { rc = fail(QMM_EHIP, "chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); break; }
+                c->chain_attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(c->cus), dim3(CHAIN_NW * WAVE), total, st, a);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { rc = fail(QMM_EHIP, "chain launch: %s", hipGetErrorString(e)); break; }
+            c->chain_launches++;
+            c->chain_steps += (int) n;
+        }
+        i += n;
+    }
+    v.clear();
+    return rc;
+}
+
+// Record one group call (one token) as one step per activation format.  Returns 1 when recorded, 0 when the call is not eligible
+// (the caller flushes and launches it the ordinary way), < 0 on error.
+static int chain_record(qmm_ctx * c, hipStream_t st, const qmm_weight * ws, int nw, int64_t K, const float * x, int64_t ldx, const qmm_mv_extra * ex) {
+    if (nw > MV_MAX_GROUP) return 0;
+    const int W = c->cus * CHAIN_NW;
+    int fams[2] = { 0, 0 };
+    int64_t rows = 0;
+    for (int i = 0; i < nw; ++i) {
+        if (ws[i].M <= 0) return 0;
+        const bool kq = ws[i].type == T_Q4_K || ws[i].type == T_Q5_K || ws[i].type == T_Q6_K;
+        fams[kq ? 1 : 0]++;
+        rows += ws[i].M;
+        // a result on top of the activations is a race between workgroups in any launch form: leave it to the caller's order
+        const char * d0 = (const char *) ws[i].dst, * x0 = (const char *) x;
+        if (d0 < x0 + K * 4 && x0 < d0 + ws[i].M * 4) return 0;
+    }
+    if (fams[1] && K % 256) return 0;
+    if ((rows + W - 1) / W > CHAIN_RPW) return 0;
+    if (ex && ex->swiglu && fams[0] && fams[1]) return 0;
+    if (chain_act_bytes(fams[1] ? CHAIN_FAM_Q8_K : CHAIN_FAM_Q8_0, 1, (int) K) + (ex && ex->norm_w ? (size_t) K * 4 : 0) + CHAIN_SLAB + 1024 > 150 * 1024) return 0;
+    if (c->chain->empty()) c->chain_stream = st;
+    else if (c->chain_stream != st) { int rc = chain_launch(c); if (rc) return rc; c->chain_stream = st; }
+    bool first = true;
+    for (int fam = 1; fam >= 0; --fam) {
+        if (!fams[fam]) continue;
+        ChainStep s;
+        memset(&s, 0, sizeof(s));
+        int r = 0;
+        for (int i = 0; i < nw; ++i) {
+            const bool kq = ws[i].type == T_Q4_K || ws[i].type == T_Q5_K || ws[i].type == T_Q6_K;
+            if ((kq ? 1 : 0) != fam) continue;
+            const int k = s.g.n++;
+            s.g.w[k] = (const uint8_t *) ws[i].w;  s.g.dst[k] = ws[i].dst;  s.g.row_bytes[k] = ws[i].w_row_bytes;  s.g.ldd[k] = ws[i].ldd;
+            s.g.type[k] = ws[i].type;
+            r += (int) ws[i].M;
+            s.g.row_end[k] = r;
+            s.g.res[k] = ex ? ex->residual[i] : nullptr;
+        }
+        if (ex) { s.g.norm_w = ex->norm_w; s.g.norm_eps = ex->norm_eps; s.g.swiglu = ex->swiglu; }
+        s.x = x;  s.ldx = ldx;  s.K = (int) K;  s.fam = fam;
+        s.dep = first ? 1 : 0;                          // the second format of one call reads the same x and writes other rows
+        s.restage = 1;
+        first = false;
+        c->chain->push_back(s);
+    }
+    return 1;
+}
+
+int qmm_internal_chain_flush(qmm_ctx * c) { return c->chain_on ? chain_launch(c) : QMM_OK; }
+
 extern "C" {
 
-int qmm_abi_version(void) { return 1; }
+int qmm_abi_version(void) { return 2; }
 
 const char * qmm_last_error(void) { return last_error().c_str(); }
 
@@ -156,6 +273,13 @@ qmm_ctx * qmm_create(int device) {
         delete c;
         return nullptr;
     }
+    c->chain = new std::vector<ChainStep>();
+    if (hipMalloc((void **) &c->chain_sync, sizeof(ChainSync)) != hipSuccess || hipMemset(c->chain_sync, 0, sizeof(ChainSync)) != hipSuccess) {
+        fail(QMM_EHIP, "qmm_create: chain state setup failed");
+        delete c->chain;
+        delete c;
+        return nullptr;
+    }
     for (int j = 0; j < n; ++j) {                                   // row split copies between devices: peer access, best effort
         int can = 0;
         if (j != device && hipDeviceCanAccessPeer(&can, device, j) == hipSuccess && can) {
@@ -170,6 +294,8 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->act_mode = atoi(e) ? QMM_ACT_X86 : QMM_ACT_REF;
     e = getenv("GGML_MI355X_MV_KMIX");
     if (e) c->mv_kmix = atoi(e);
+    e = getenv("GGML_MI355X_CHAIN");
+    if (e) c->chain_enabled = atoi(e);
     e = getenv("GGML_MI355X_MV_BPC");
     if (e && atoi(e) >= 1 && atoi(e) <= 8) c->mv_bpc = atoi(e);
     e = getenv("GGML_MI355X_MM_GROUP");
@@ -191,6 +317,8 @@ void qmm_destroy(qmm_ctx * c) {
     (void) hipDeviceSynchronize();
     if (c->ws) (void) hipFree(c->ws);
     if (c->flag) (void) hipFree(c->flag);
+    if (c->chain_sync) (void) hipFree(c->chain_sync);
+    delete c->chain;
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -255,18 +383,21 @@ void qmm_host_free(qmm_ctx * c, void * p) {
 }
 int qmm_memcpy_h2d(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->s(st)));
     HIP_TRY(hipStreamSynchronize(c->s(st)));
     return QMM_OK;
 }
 int qmm_memcpy_d2h(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->s(st)));
     HIP_TRY(hipStreamSynchronize(c->s(st)));
     return QMM_OK;
 }
 int qmm_memcpy_d2d(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->s(st)));
     return QMM_OK;
 }
@@ -274,12 +405,14 @@ struct qmm_event { hipEvent_t ev; };
 int qmm_memcpy_h2d_async(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
     if (!c) return fail(QMM_EINVAL, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->s(st)));
     return QMM_OK;
 }
 int qmm_memcpy_d2h_async(qmm_ctx * c, void * dst, const void * src, size_t n, void * st) {
     if (!c) return fail(QMM_EINVAL, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->s(st)));
     return QMM_OK;
 }
@@ -293,6 +426,7 @@ int qmm_memcpy2d_d2d(qmm_ctx * c, void * dst, size_t dpitch, const void * src, s
     if (!c) return fail(QMM_EINVAL, "null ctx");
     if (width == 0 || height == 0) return QMM_OK;
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     if (dpitch == width && spitch == width) HIP_TRY(hipMemcpyAsync(dst, src, width * height, hipMemcpyDeviceToDevice, c->s(st)));
     else HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, c->s(st)));
     return QMM_OK;
@@ -316,23 +450,37 @@ void qmm_event_destroy(qmm_ctx * c, qmm_event * e) {
 int qmm_event_record(qmm_ctx * c, qmm_event * e, void * st) {
     if (!c || !e) return fail(QMM_EINVAL, "qmm_event_record: null argument");
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     HIP_TRY(hipEventRecord(e->ev, c->s(st)));
     return QMM_OK;
 }
 int qmm_stream_wait_event(qmm_ctx * c, void * st, qmm_event * e) {
     if (!c || !e) return fail(QMM_EINVAL, "qmm_stream_wait_event: null argument");
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     HIP_TRY(hipStreamWaitEvent(c->s(st), e->ev, 0));
     return QMM_OK;
 }
 int qmm_memset(qmm_ctx * c, void * dst, int v, size_t n, void * st) {
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     HIP_TRY(hipMemsetAsync(dst, v, n, c->s(st)));
     return QMM_OK;
 }
 int qmm_synchronize(qmm_ctx * c, void * st) {
     HIP_TRY(hipSetDevice(c->device));
+    if (c->chain_on && !c->chain->empty()) { int rc = chain_launch(c); if (rc) return rc; }       // nothing recorded stays behind a wait
     HIP_TRY(hipStreamSynchronize(c->s(st)));
+    if (c->chain_launches != c->chain_checked) {
+        uint32_t err = 0;
+        HIP_TRY(hipMemcpy(&err, &c->chain_sync->err[0], sizeof(err), hipMemcpyDeviceToHost));
+        c->chain_checked = c->chain_launches;
+        if (err) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemset(c->chain_sync, 0, sizeof(ChainSync)));
+            return fail(QMM_EHIP, "chain: a grid-wide wait timed out (workgroups not co-resident?); results of that launch are undefined");
+        }
+    }
     int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
@@ -355,6 +503,7 @@ int qmm_dequantize(qmm_ctx * c, int type, const void * w, int64_t rb, int64_t ro
     if (rb < (int64_t) qmm_row_size(type, K)) return fail(QMM_EINVAL, "qmm_dequantize: row stride too small");
     if ((uintptr_t) dst % 16) return fail(QMM_EINVAL, "qmm_dequantize: dst must be 16-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     hipStream_t s = c->s(st);
     switch (type) {
         case T_Q4_0: return launch_dequant<T_Q4_0>(s, w, rb, rows, K, dst);
@@ -374,6 +523,7 @@ int qmm_quantize_act(qmm_ctx * c, int vt, const float * x, int64_t rows, int64_t
         return fail(QMM_EINVAL, "qmm_quantize_act: K/ldx/alignment");
     if (rows == 0) return QMM_OK;
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     const int rpb = 4;
     dim3 grid((unsigned) ((rows + rpb - 1) / rpb));
     if (vt == T_Q8_0)
@@ -414,6 +564,14 @@ static int mul_mat_group_impl(qmm_ctx * c, const qmm_weight * ws, int nw, int64_
         int rc = check_mm(ws[i].type, ws[i].w, ws[i].w_row_bytes, K, x, ldx, "qmm_mul_mat");
         if (rc) return rc;
         if (ws[i].M < 0 || ws[i].ldd < ws[i].M) return fail(QMM_EINVAL, "qmm_mul_mat: ldd < M");
+    }
+    if (c->chain_on) {
+        // recording (qmm_chain_begin): one-token groups are collected; anything else goes out behind what was collected
+        int rec = N == 1 ? chain_record(c, st, ws, nw, K, x, ldx, ex) : 0;
+        if (rec < 0) return rec;
+        if (rec == 1) return QMM_OK;
+        int rc = chain_launch(c);
+        if (rc) return rc;
     }
     if (N <= QMM_MATVEC_MAX_N && nw >= 2 && nw <= MV_MAX_GROUP && c->mv_kmix) {
         // K-quant matrices of different types share the Q8_K activations: one mixed-type launch for the whole group
@@ -538,6 +696,7 @@ int qmm_mul_mat_id(qmm_ctx * c, int type, const void * as, int64_t rb, int64_t e
         return fail(QMM_EINVAL, "qmm_mul_mat_id: strides / ne11");
     if (n_tokens <= 0 || n_used <= 0 || M <= 0) return QMM_OK;
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     return moe_mul_mat_id(c, c->s(stream), type, as, rb, expert_bytes, K, M, n_expert, b, ne11, b_nb1, b_nb2,
                           ids, n_used, n_tokens, ids_nb1, dst, d_nb1, d_nb2);
 }
@@ -555,8 +714,43 @@ int qmm_mul_mat_id_pair(qmm_ctx * c, int type, const void * as0, const void * as
         return fail(QMM_EINVAL, "qmm_mul_mat_id_pair: strides / ne11");
     if (n_tokens <= 0 || n_used <= 0 || M <= 0) return QMM_OK;
     HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
     return moe_mul_mat_id(c, c->s(stream), type, as0, rb, expert_bytes, K, M, n_expert, b, ne11, b_nb1, b_nb2,
                           ids, n_used, n_tokens, ids_nb1, dst0, d_nb1, d_nb2, as1, dst1);
+}
+
+int qmm_chain_begin(qmm_ctx * c) {
+    if (!c) return fail(QMM_EINVAL, "qmm_chain_begin: NULL context");
+    if (c->chain_on) return fail(QMM_EINVAL, "qmm_chain_begin: already recording");
+    c->chain_on = c->chain_enabled != 0;
+    return QMM_OK;
+}
+int qmm_chain_flush(qmm_ctx * c) {
+    if (!c) return fail(QMM_EINVAL, "qmm_chain_flush: NULL context");
+    if (!c->chain_on) return QMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    return chain_launch(c);
+}
+int qmm_chain_end(qmm_ctx * c) {
+    if (!c) return fail(QMM_EINVAL, "qmm_chain_end: NULL context");
+    int rc = QMM_OK;
+    if (c->chain_on) {
+        HIP_TRY(hipSetDevice(c->device));
+        rc = chain_launch(c);
+    }
+    c->chain_on = false;
+    return rc;
+}
+int qmm_chain_debug(qmm_ctx * c, void * stamps) {
+    if (!c) return fail(QMM_EINVAL, "qmm_chain_debug: NULL context");
+    c->chain_dbg = (uint64_t *) stamps;
+    return QMM_OK;
+}
+int qmm_chain_stats(const qmm_ctx * c, int * launches, int * steps) {
+    if (!c) return fail(QMM_EINVAL, "qmm_chain_stats: NULL context");
+    if (launches) *launches = c->chain_launches;
+    if (steps) *steps = c->chain_steps;
+    return QMM_OK;
 }
 
 } // extern "C"

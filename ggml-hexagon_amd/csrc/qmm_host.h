@@ -11,6 +11,9 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
+
+namespace qmm { struct ChainStep; struct ChainSync; }
 
 struct qmm_ctx {
     int         device = 0;
@@ -31,11 +34,30 @@ struct qmm_ctx {
     const float * prep_x2 = nullptr; // transient: second operand of a SwiGLU input while qmm_mul_mat_swiglu_in runs (prefill prep)
     int64_t     prep_ldx2 = 0;
     int         splitk = 1;          // split K over workgroups when a MUL_MAT has too few tiles (GGML_MI355X_SPLITK=0: off)
+    // chains (qmm_chain.hiph): while recording, one-token MUL_MAT groups are collected instead of launched
+    int         chain_enabled = 1;   // GGML_MI355X_CHAIN=0: qmm_chain_begin records nothing, every group is its own launch
+    bool        chain_on = false;
+    std::vector<qmm::ChainStep> * chain = nullptr;
+    qmm::ChainSync * chain_sync = nullptr;      // device: arrival counters, generation, error word
+    int         chain_launches = 0;  // persistent launches issued so far (tests / bench read it through qmm_chain_stats)
+    int         chain_steps = 0;
+    uint64_t *  chain_dbg = nullptr;  // qmm_chain_debug: device buffer the next persistent launches stamp their phases into
+    bool        chain_attr_set = false;      // the kernel's dynamic-LDS limit has been raised on this device
+    int         chain_checked = 0;   // chain_launches when the error word was last read
+    hipStream_t chain_stream = nullptr;         // stream of the recorded steps
     char        name[128] = {0};
 
     // `st` is used verbatim: NULL is HIP's default stream (what torch's default stream is), not ours
     hipStream_t s(void * st) const { return (hipStream_t) st; }
 };
+
+// launches what a recording context has collected (qmm_chain_begin); every entry point that queues other work calls it first, so
+// stream order is the order of the calls whether or not a chain is being recorded.  Defined in qmm_api.hip.
+int qmm_internal_chain_flush(qmm_ctx * c);
+#define QMM_CHAIN_FLUSH(c)                                                      \
+    do {                                                                        \
+        if ((c)->chain_on) { int rc_ = qmm_internal_chain_flush(c); if (rc_) return rc_; } \
+    } while (0)
 
 namespace qmm {
 

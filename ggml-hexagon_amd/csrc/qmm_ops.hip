@@ -1469,6 +1469,7 @@ int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * a, const qmm_tensor
     if (!ctx || !d) return fail(QMM_EINVAL, "qmm_op_compute: NULL context or dst");
     if (!qmm_op_supported(op, a, b, c, d)) return fail(QMM_EUNSUPPORTED, "qmm_op_compute: op %d with these types / shapes / strides is not implemented", op);
     HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
     hipStream_t st = ctx->s(stream);
     switch (op) {
         case QMM_OP_ADD: return launch_binary<QMM_OP_ADD>(st, a, b, d);
@@ -1566,6 +1567,7 @@ int qmm_op_add_rms_norm(qmm_ctx * ctx, const qmm_tensor * a, const qmm_tensor * 
                         const qmm_tensor * dst, float eps, void * stream) {
     if (!ctx || !qmm_op_add_rms_norm_supported(a, b, w, sum, dst)) return fail(QMM_EUNSUPPORTED, "qmm_op_add_rms_norm: operands not supported");
     HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
     return launch_rms_norm(ctx->s(stream), a, b, w, dst, sum, eps);
 }
 
@@ -1587,6 +1589,7 @@ int qmm_attn_decode(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, c
     if (!ctx || !qmm_attn_decode_supported(q, k, v, mask, dst)) return fail(QMM_EUNSUPPORTED, "qmm_attn_decode: operands not supported");
     if ((uintptr_t) k->data % 16 || (uintptr_t) v->data % 16) return fail(QMM_EINVAL, "qmm_attn_decode: K / V must be 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
     AttnArgs g;
     g.q = (const char *) q->data; g.k = (const char *) k->data; g.v = (const char *) v->data; g.mask = (const char *) mask->data; g.dst = (char *) dst->data;
     g.q_nb1 = q->nb[1]; g.q_nb2 = q->nb[2]; g.k_nb1 = k->nb[1]; g.k_nb2 = k->nb[2]; g.v_nb1 = v->nb[1]; g.v_nb2 = v->nb[2];
@@ -1644,6 +1647,7 @@ int qmm_rope_kv_store(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * po
                       const qmm_tensor * k, const qmm_tensor * k_dst, const qmm_tensor * v, const qmm_tensor * v_dst, void * stream) {
     if (!ctx || !qmm_rope_kv_store_supported(q, pos, ff, q_dst, k, k_dst, v, v_dst)) return fail(QMM_EUNSUPPORTED, "qmm_rope_kv_store: operands not supported");
     HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
     RopeStoreArgs g;
     g.q = (const char *) q->data; g.qd = (char *) q_dst->data; g.sq = shape_of(q); g.sqd = shape_of(q_dst);
     g.k = k ? (const char *) k->data : nullptr; g.kd = k ? (char *) k_dst->data : nullptr; g.sk = shape_of(k ? k : q); g.skd = shape_of(k ? k_dst : q_dst);
@@ -1682,6 +1686,7 @@ int qmm_attn_prefill(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, 
     if (!ctx || !qmm_attn_prefill_supported(q, k, v, mask, dst)) return fail(QMM_EUNSUPPORTED, "qmm_attn_prefill: operands not supported");
     if ((uintptr_t) k->data % 16 || (uintptr_t) v->data % 16 || (uintptr_t) q->data % 16) return fail(QMM_EINVAL, "qmm_attn_prefill: q / K / V must be 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
     AttnArgs g;
     g.q = (const char *) q->data; g.k = (const char *) k->data; g.v = (const char *) v->data; g.mask = (const char *) mask->data; g.dst = (char *) dst->data;
     g.q_nb1 = q->nb[1]; g.q_nb2 = q->nb[2]; g.k_nb1 = k->nb[1]; g.k_nb2 = k->nb[2]; g.v_nb1 = v->nb[1]; g.v_nb2 = v->nb[2];
@@ -1734,6 +1739,7 @@ int qmm_attn_decode_rope(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor *
         return fail(QMM_EUNSUPPORTED, "qmm_attn_decode_rope: operands not supported");
     if ((uintptr_t) k->data % 16 || (uintptr_t) v->data % 16) return fail(QMM_EINVAL, "qmm_attn_decode_rope: K / V must be 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
     AttnArgs g;
     g.q = (const char *) q->data; g.k = (const char *) k->data; g.v = (const char *) v->data; g.mask = (const char *) mask->data; g.dst = (char *) dst->data;
     g.q_nb1 = q->nb[2]; g.q_nb2 = q->nb[1];                                  // token stride, head stride of the un-permuted q
@@ -1777,6 +1783,7 @@ int qmm_moe_router(qmm_ctx * ctx, const qmm_tensor * logits, const qmm_tensor * 
                    void * stream) {
     if (!ctx || !qmm_moe_router_supported(logits, ids, weights, n_used)) return fail(QMM_EUNSUPPORTED, "qmm_moe_router: operands not supported");
     HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
     const int N = (int) logits->ne[1];
     hipLaunchKernelGGL(moe_router_kernel, dim3((N + 3) / 4), dim3(256), 0, ctx->s(stream), (const char *) logits->data, (char *) ids->data,
                        (char *) weights->data, logits->nb[1], ids->nb[1], (int64_t) n_used * 4, (int) logits->ne[0], (int) n_used, N, normalise);
@@ -1797,6 +1804,7 @@ int qmm_moe_combine(qmm_ctx * ctx, const qmm_tensor * x, const qmm_tensor * w, c
     if (!ctx || !qmm_moe_combine_supported(x, w, out)) return fail(QMM_EUNSUPPORTED, "qmm_moe_combine: operands not supported");
     if ((uintptr_t) x->data % 16 || (uintptr_t) out->data % 16) return fail(QMM_EINVAL, "qmm_moe_combine: x / out must be 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
     const int E = (int) x->ne[0];
     hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned) ((E / 4 + 255) / 256), (unsigned) x->ne[2]), dim3(256), 0, ctx->s(stream), (const char *) x->data,
                        (const char *) w->data, (char *) out->data, x->nb[1], x->nb[2], w->nb[1], w->nb[2], out->nb[1], E, (int) x->ne[1]);

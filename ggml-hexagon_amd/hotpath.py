@@ -35,6 +35,7 @@ class HotPath:
                     w = synth.synth_weights_torch(m.type, hi - lo, m.K, device, seed + 1000 * rank + i)
                     self.weights[m.name] = (w, ranges)
         self.io = {}
+        self.chain = False       # persistent chains for token generation (bench.py --chain): measured slower than launches, DESIGN.md
 
     def weight_bytes_local(self) -> int:
         return sum(w.numel() for w, _ in self.weights.values())
@@ -79,6 +80,19 @@ class HotPath:
         io_all = self.prepare(n_tokens)
         io_out = io_all if n_outputs is None or n_outputs >= n_tokens else self.prepare(n_outputs)
         q = self.q
+        # token generation on one GPU: the pass is one chain of dependent groups (every MUL_MAT of a decode step consumes what the
+        # previous one produced, through the glue ops), issued as persistent launches (csrc/qmm_chain.hiph).  The row split keeps
+        # one launch per group: an RCCL concat sits between two groups.
+        chain = self.chain and n_tokens == 1 and self.world == 1
+        if chain:
+            q.chain_begin()
+        try:
+            self._issue(q, io_all, io_out)
+        finally:
+            if chain:
+                q.chain_end()
+
+    def _issue(self, q, io_all, io_out):
         for grp in self.wl.groups:
             x, dst_local, dst_full, ids = io_out if grp.outputs_only else io_all
             m0 = grp.mats[0]

@@ -163,6 +163,25 @@ typedef struct qmm_mv_extra {
 QMM_API int qmm_mul_mat_group_ex(qmm_ctx * ctx, const qmm_weight * ws, int n_weights, int64_t K,
                                  const float * x, int64_t N, int64_t ldx, const qmm_mv_extra * extra, void * stream);
 
+/* Chains: a run of DEPENDENT one-token MUL_MAT groups as one persistent launch (token generation: wo -> ffn_gate/up -> ffn_down ->
+ * the next layer's wq/wk/wv have nothing between them once the norm, the residual add and the SwiGLU are folded in, and every
+ * launch of its own idles HBM for ~3.5 us of boundary, ramp and first-slice latency).  Between qmm_chain_begin and qmm_chain_end,
+ * qmm_mul_mat_group / _ex calls with N == 1 are RECORDED, not launched; every other entry point of this library (and
+ * qmm_chain_flush / _end / qmm_synchronize) first launches what was recorded, so the stream sees the calls in their order.  Inside a
+ * persistent launch step s+1 starts after every workgroup has published step s (agent-scope arrival counters, write-through
+ * stores, sc1 loads), and each wave requests its first weights of step s+1 before that wait.  Results are bit-identical to the
+ * same calls made outside a recording.  A launch needs one resident workgroup per CU; a wait that cannot complete times out
+ * (20 ms) and qmm_synchronize then returns QMM_EHIP.  GGML_MI355X_CHAIN=0 turns recording off (qmm_chain_begin becomes a no-op).
+ * The reference has no counterpart: its AP->cDSP boundary is one FastRPC round trip per MUL_MAT (kernels/ggmlop_ap_skel.c:380-450). */
+QMM_API int qmm_chain_begin(qmm_ctx * ctx);
+QMM_API int qmm_chain_flush(qmm_ctx * ctx);
+QMM_API int qmm_chain_end(qmm_ctx * ctx);
+QMM_API int qmm_chain_stats(const qmm_ctx * ctx, int * persistent_launches, int * steps_in_them);
+/* diagnostics: the following persistent launches write, per step and workgroup, 8 uint64 stamps of the 100 MHz clock (step start,
+ * wait over, activations staged, ..., results published) to `stamps` ([steps][compute units][8], device memory, consecutive
+ * launches behind each other); NULL switches it off.  profiles/tools/chain_stamps.py reads them. */
+QMM_API int qmm_chain_debug(qmm_ctx * ctx, void * stamps);
+
 /* dst = W * (silu(gate) .* up) for a prompt batch (N > QMM_MATVEC_MAX_N): ffn_down with build_ffn's SwiGLU product formed by the
  * activation prep of the MFMA path; gate / up rows are ld_gate / ld_up floats apart.  Default prefill precision only. */
 QMM_API int qmm_mul_mat_swiglu_in(qmm_ctx * ctx, int type, const void * w, int64_t w_row_bytes, int64_t K, int64_t M,
