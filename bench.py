@@ -93,37 +93,87 @@ def roofline_leg(hp, q, n_batch, torch, n_outputs=None):
     return agg
 
 
-def llama_bench_cpu(name, threads=16):
-    """Part of the cpu_baseline leg: the reference's own libllama (oracle/_ref, unmodified) on its CPU backend, llama-bench's
-    protocol through tests/cpp/llama_e2e.cpp, on a bounded sample (one pp512 after the warm-up, 16 generated tokens): the whole
-    model end to end (attention, norms, sampling-free decode), not only its MUL_MATs.  None when the binary is not there."""
-    import json as _json
-    import shutil
-    import subprocess
-    import tempfile
-    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "llama-e2e")
-    if not os.path.exists(exe) or name.startswith(("mixtral", "llama3-70b")) or shutil.disk_usage(tempfile.gettempdir()).free < (12 << 30):
-        return None
-    tmp = tempfile.mkdtemp(prefix="qmm_bench_")
+class LlamaBench:
+    """The reference's own libllama (oracle/_ref, compiled unmodified from /root/reference) driven through llama-bench's protocol
+    (examples/llama-bench/llama-bench.cpp:1430-1468, 1605-1642; tests/cpp/llama_e2e.cpp): warm-up, llama_kv_self_clear, one llama_decode
+    of 512 random tokens, 128 single-token decodes with a synchronize each.  Always a child process (never an exec of this one, which
+    holds the GPU).  `gpu` loads the MI355X module through GGML_BACKEND_PATH with every layer offloaded; otherwise -ngl 0 on the ggml
+    CPU backend, which is the CPU baseline SURVEY 8(d) defines.  The synthetic GGUF is written once and shared by both legs."""
+
+    def __init__(self, name):
+        import shutil
+        import tempfile
+        self.name = name
+        self.exe = ROOT / "oracle" / "_ref" / "llama-e2e"
+        self.plugin = ROOT / "ggml-hexagon_amd" / "libggml-mi355x.so"
+        self.ok = self.exe.exists() and not name.startswith("llama3-70b") and shutil.disk_usage(tempfile.gettempdir()).free >= (60 << 30 if name.startswith("mixtral") else 12 << 30)
+        self.tmp = tempfile.mkdtemp(prefix="qmm_bench_") if self.ok else None
+        self.gguf = None
+
+    def _run(self, args, env, timeout):
+        import subprocess
+        p = subprocess.run([str(self.exe), *args], check=True, capture_output=True, text=True, timeout=timeout, env=env, cwd=str(self.exe.parent))
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        return (json.loads(lines[-1]) if lines else None), p.stderr
+
+    def _env(self, gpu, extra=None):
+        env = {k: v for k, v in os.environ.items() if k != "GGML_BACKEND_PATH"}
+        if gpu:
+            env["GGML_BACKEND_PATH"] = str(self.plugin)
+        env.update(extra or {})
+        return env
+
+    def write(self):
+        if self.gguf is None:
+            self.gguf = os.path.join(self.tmp, "m.gguf")
+            self._run(["write", "--config", self.name, "--gguf", self.gguf], self._env(False), 300)
+        return self.gguf
+
+    def run(self, gpu, threads, n_prompt=512, n_gen=128, reps=3, timeout=300):
+        if not self.ok or (gpu and not self.plugin.exists()):
+            return None
+        try:
+            gguf = self.write()
+            r, _ = self._run(["bench", "--gguf", gguf, "--ngl", "99" if gpu else "0", "-p", str(n_prompt), "-n", str(n_gen), "-r", str(reps), "-t", str(threads)],
+                             self._env(gpu), timeout)
+            out = {"pp512_tok_s": r["pp_tok_s"], "tg128_tok_s" if n_gen == 128 else "tg_tok_s": r["tg_tok_s"], "reps": reps, "threads": threads,
+                   "n_gen": n_gen, "devices": r.get("devices")}
+            if gpu:
+                # the same protocol once more with the module timing every graph on its stream (event pair around the launches of a
+                # graph_compute): GPU time per token / per prompt batch, i.e. what of the end-to-end time is not the host's
+                _, err = self._run(["bench", "--gguf", gguf, "--ngl", "99", "-p", str(n_prompt), "-n", "64", "-r", "1", "-t", str(threads)],
+                                   self._env(True, {"GGML_MI355X_TIMING": "1"}), timeout)
+                import re
+                m = re.search(r"tg graphs (\d+) stream_ms ([0-9.]+) \| pp graphs (\d+) tokens (\d+) stream_ms ([0-9.]+)", err)
+                if m:
+                    ntg, mtg, npp, tpp, mpp = int(m.group(1)), float(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5))
+                    out["gpu_ms_per_token"] = round(mtg / max(ntg, 1), 4)
+                    out["gpu_ms_per_prompt_batch"] = round(mpp / max(npp, 1), 3)
+            return out
+        except Exception as e:              # reported-only
+            return {"pp512_tok_s": None, "tg128_tok_s": None, "threads": threads, "error": f"{type(e).__name__}: {str(e)[-300:]}"}
+
+    def close(self):
+        import shutil
+        if self.tmp:
+            shutil.rmtree(self.tmp, ignore_errors=True)
+
+
+def cpu_model():
     try:
-        gguf = os.path.join(tmp, "m.gguf")
-        env = {k: v for k, v in os.environ.items() if k != "GGML_BACKEND_PATH"}          # CPU backend only
-        subprocess.run([exe, "write", "--config", name, "--gguf", gguf], check=True, capture_output=True, timeout=120, env=env)
-        p = subprocess.run([exe, "bench", "--gguf", gguf, "--ngl", "0", "-p", "512", "-n", "16", "-r", "1", "-t", str(threads)],
-                           check=True, capture_output=True, text=True, timeout=240, env=env)
-        r = _json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-        return {"pp512_tok_s": r["pp_tok_s"], "tg_tok_s": r["tg_tok_s"], "threads": threads, "kind": "reference",
-                "sample": "llama_model_load + llama_decode of the reference's libllama on the ggml CPU backend: warm-up, one pp512, 16 generated tokens"}
-    except Exception as e:              # reported-only
-        return {"pp512_tok_s": None, "tg_tok_s": None, "threads": threads, "kind": "reference", "sample": f"failed: {e}"}
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(wl, cores):
-    """the reference's CPU backend (oracle/_ref, built from /root/reference) or, failing that, our C port, timed on
-    this host on a bounded sample: the MUL_MATs of one 'more-bits' and one ordinary layer + the output projection
-    at N=1, one ordinary layer at N=512; extrapolated over the layers"""
+def cpu_baseline(wl, cores, lb):
+    """the same llama-bench protocol with -ngl 0 (the reference's libllama on its ggml CPU backend, threads = this
+    box's CPU share) is the baseline `value`.  Beside it, under `matmul_only`, the MUL_MAT path alone: the reference's CPU backend
+    (oracle/_ref) or, failing that, our C port, timed on a bounded sample: each distinct (type, K, M) once at N=1 and N=512,
+    summed over the model"""
     import numpy as np
     from oracle.pyoracle import Oracle, RefGgml, ref_available
     from ggml_hexagon_amd import synth
@@ -166,13 +216,20 @@ def cpu_baseline(wl, cores):
             t_pp += dp * (M / Mp) * count
         else:
             t_pp = float("nan")
-    e2e = llama_bench_cpu(wl.name)
-    return {"value": round(1.0 / t_tg, 3), "unit": "tok/s (tg128)", "pp512_tok_s": None if t_pp != t_pp else round(512.0 / t_pp, 2),
-            "llama_bench_protocol": e2e,
-            "cores": cores, "kind": kind, "variant": getattr(ref, "variant", "scalar+omp"),
-            "sample": f"each distinct (type,K,M) of {wl.name} once at N=1 (x3) and N=512 (rows capped at 16384/4096, scaled), "
+    threads = min(cores, 16)
+    e2e = lb.run(False, threads, n_gen=16, reps=1) if lb is not None else None
+    mm = {"tg128_tok_s": round(1.0 / t_tg, 3), "pp512_tok_s": None if t_pp != t_pp else round(512.0 / t_pp, 2), "threads": cores,
+          "kind": kind, "variant": getattr(ref, "variant", "scalar+omp"),
+          "sample": f"each distinct (type,K,M) of {wl.name} once at N=1 (x3) and N=512 (rows capped at 16384/4096, scaled), "
                       f"summed over the model's {len(mats)} MUL_MATs ({per_layer} per layer); prompt pass as llama-bench runs it: "
                       f"last layer's FFN and the output projection at n_outputs = 1"}
+    if e2e and e2e.get("tg_tok_s"):
+        return {"value": e2e["tg_tok_s"], "unit": "tok/s (tg, llama-bench protocol, -ngl 0)", "pp512_tok_s": e2e["pp512_tok_s"], "cores": threads,
+                "kind": "reference", "cpu": cpu_model(),
+                "sample": "the reference's libllama on the ggml CPU backend, whole model end to end: warm-up, one pp512, 16 generated tokens (1 rep)",
+                "matmul_only": mm}
+    return {"value": mm["tg128_tok_s"], "unit": "tok/s (tg128, MUL_MAT path only)", "pp512_tok_s": mm["pp512_tok_s"], "cores": cores, "kind": kind,
+            "cpu": cpu_model(), "sample": mm["sample"], "llama_bench_protocol": e2e}
 
 
 def main():
@@ -184,6 +241,7 @@ def main():
     ap.add_argument("--n-prompt", type=int, default=512)
     ap.add_argument("--n-gen", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (llama-bench protocol through libllama: device and CPU)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--chain", action="store_true", help="token generation as persistent chains (csrc/qmm_chain.hiph) instead of one launch per MUL_MAT group")
     ap.add_argument("--all-logits", action="store_true",
@@ -284,14 +342,20 @@ def main():
 
     k1, nb1, fl1, s1, c1 = dominant(agg1)
     kp, nbp, flp, sp, cp = dominant(aggp, batched=True)
+    kernel1 = f"qmm::matvec_kernel<{NAMES.get(k1[1], k1[1])},1>" if k1[0] == "mm" else f"qmm::matvec_id_kernel<{NAMES.get(k1[1])}>"
     traffic = None
     tf = ROOT / "profiles" / "pmc_traffic.json"
     if tf.exists():
+        # HBM bytes per launch from the PMC passes (profiles/README.md): only when that file was measured on THIS kernel
+        # (its name, template arguments included, as rocprofv3 prints it) and this workload
         try:
-            traffic = json.loads(tf.read_text()).get("matvec_bytes_per_launch")
+            tj = json.loads(tf.read_text())
+            want = f"matvec_kernel<{k1[1]}, 1, false>" if k1[0] == "mm" else None
+            if want and want in tj.get("kernel", "") and tj.get("workload") == wl.name:
+                traffic = tj.get("matvec_bytes_per_launch")
         except Exception:
             traffic = None
-    roof = {"bound": "hbm", "kernel": f"qmm::matvec_kernel<{NAMES.get(k1[1], k1[1])},1>" if k1[0] == "mm" else f"qmm::matvec_id_kernel<{NAMES.get(k1[1])}>",
+    roof = {"bound": "hbm", "kernel": kernel1,
             "achieved": round(nb1 / s1 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb1 / s1 / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": traffic, "launches": c1, "avg_launch_us": round(s1 / c1 * 1e6, 2), "algo_bytes_per_launch": int(nb1 / c1),
             "all_tg_launches_GBs": round(sum(a[0] for a in agg1.values()) / sum(a[2] for a in agg1.values()) / 1e9, 1)}
@@ -318,12 +382,22 @@ def main():
         "pp_algo_TFLOPs": round(wl.flops(args.n_prompt, n_out_pp) / world / pp_s / 1e12, 1),
         "roofline": roof, "roofline_pp": roof_pp,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_e2e:
+        lb = LlamaBench(wl.name)
         try:
             cores = min(len(os.sched_getaffinity(0)), 64)
-            out["cpu_baseline"] = cpu_baseline(wl, cores)
-        except Exception as e:          # the baseline is reported-only; never let it take the GPU numbers down
-            out["cpu_baseline"] = {"value": None, "unit": "tok/s (tg128)", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+            # the metric BASELINE.json names, end to end: the reference's unmodified libllama with this module loaded, all layers on
+            # the device (attention, norms, KV cache, host-side graph build and sampling-free decode included)
+            e2e = lb.run(True, min(cores, 16))
+            if e2e is not None:
+                out["e2e"] = e2e
+            if not args.no_cpu_baseline:
+                try:
+                    out["cpu_baseline"] = cpu_baseline(wl, cores, lb)
+                except Exception as e:          # the baseline is reported-only; never let it take the GPU numbers down
+                    out["cpu_baseline"] = {"value": None, "unit": "tok/s (tg128)", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        finally:
+            lb.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -16,7 +16,7 @@ EXPORTS = [
     "qmm_abi_version", "qmm_last_error", "qmm_device_count", "qmm_create", "qmm_destroy", "qmm_device", "qmm_stream",
     "qmm_device_info", "qmm_set_act_mode", "qmm_set_precision", "qmm_malloc", "qmm_free", "qmm_host_malloc", "qmm_host_free", "qmm_memcpy_h2d",
     "qmm_memcpy_d2h", "qmm_memcpy_d2d", "qmm_memset", "qmm_synchronize", "qmm_memcpy2d_d2d", "qmm_event_create",
-    "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_memcpy_h2d_async",
+    "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_event_create_timing", "qmm_event_elapsed_ms", "qmm_memcpy_h2d_async",
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_dequantize",
     "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_swiglu_in", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
     "qmm_chain_begin", "qmm_chain_flush", "qmm_chain_end", "qmm_chain_stats", "qmm_chain_debug",

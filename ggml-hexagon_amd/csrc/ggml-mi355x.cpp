@@ -77,6 +77,10 @@ struct mi355x_backend_ctx {
     std::vector<swiglu_src>          swiglu_in;      // per node: this ffn_down forms silu(gate) * up in its activation prep (prompt batches)
     struct norm_req { const ggml_tensor * rn = nullptr, * mul = nullptr, * w = nullptr; int readers = 0; };
     norm_req                         pending_norm;
+    // GGML_MI355X_TIMING=1: stream time of every graph (an event pair around its launches), summed per kind of graph
+    qmm_event *                      ev_t0 = nullptr, * ev_t1 = nullptr;
+    double                           ms_tg = 0, ms_pp = 0;
+    int64_t                          graphs_tg = 0, graphs_pp = 0, tokens_pp = 0;
 };
 
 // GGML_MI355X_GLUE=0: offload the quantized MUL_MAT / MUL_MAT_ID only (the round-1 surface); GGML_MI355X_FUSE=0: no fused pairs
@@ -86,6 +90,16 @@ bool GGML_MI355X_GLUE_OFF() {
 }
 bool GGML_MI355X_ATTN_ROPE() {
     static const bool on = [] { const char * e = getenv("GGML_MI355X_ATTN_ROPE"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+bool GGML_MI355X_TIMING() {
+    static const bool on = [] { const char * e = getenv("GGML_MI355X_TIMING"); return e && atoi(e) != 0; }();
+    return on;
+}
+// GGML_MI355X_CHAIN=1: one-token MUL_MAT groups with nothing between them (wo -> ffn_gate/up -> ffn_down -> next wq/wk/wv once
+// norm, residual and SwiGLU are folded in) go out as one persistent launch (qmm_chain_*); measured slower than launches so far
+bool GGML_MI355X_CHAIN() {
+    static const bool on = [] { const char * e = getenv("GGML_MI355X_CHAIN"); return e && atoi(e) != 0; }();
     return on;
 }
 bool GGML_MI355X_FUSE_OFF() {
@@ -764,6 +778,12 @@ const char * backend_get_name(ggml_backend_t backend) { return ((mi355x_backend_
 void backend_free(ggml_backend_t backend) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     if (ctx->ev_copy) qmm_event_destroy(ctx->dev->qmm, ctx->ev_copy);
+    if (ctx->ev_t0) {
+        fprintf(stderr, "MI355X timing %s: tg graphs %lld stream_ms %.3f | pp graphs %lld tokens %lld stream_ms %.3f\n", ctx->name.c_str(),
+                (long long) ctx->graphs_tg, ctx->ms_tg, (long long) ctx->graphs_pp, (long long) ctx->tokens_pp, ctx->ms_pp);
+        qmm_event_destroy(ctx->dev->qmm, ctx->ev_t0);
+        qmm_event_destroy(ctx->dev->qmm, ctx->ev_t1);
+    }
     if (ctx->hoist_buf) {
         qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm));
         qmm_free(ctx->dev->qmm, ctx->hoist_buf);
@@ -872,6 +892,20 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         return r && r->uses == 1;
     };
     const int n_nodes = cgraph->n_nodes;
+    const bool timing = GGML_MI355X_TIMING();
+    if (timing) {
+        if (!ctx->ev_t0) { ctx->ev_t0 = qmm_event_create_timing(ctx->dev->qmm); ctx->ev_t1 = qmm_event_create_timing(ctx->dev->qmm); }
+        if (ctx->ev_t0 && ctx->ev_t1) qmm_event_record(ctx->dev->qmm, ctx->ev_t0, qmm_stream(ctx->dev->qmm));
+    }
+    const bool chain = GGML_MI355X_CHAIN() && !GGML_MI355X_FUSE_OFF();
+    if (chain && qmm_chain_begin(ctx->dev->qmm)) {
+        GGML_LOG_ERROR("MI355X graph_compute: %s\n", qmm_last_error());
+        return GGML_STATUS_FAILED;
+    }
+    struct chain_guard {            // every return path below stops the recording (and launches what was recorded)
+        qmm_ctx * q; bool on;
+        ~chain_guard() { if (on) qmm_chain_end(q); }
+    } guard{ ctx->dev->qmm, chain };
     std::vector<char> & done = ctx->done;
     done.assign(n_nodes, 0);
     std::vector<const ggml_tensor *> & deferred = ctx->deferred;
@@ -1227,10 +1261,28 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         }
         if (st != GGML_STATUS_SUCCESS) return st;
     }
+    if (chain) {
+        guard.on = false;
+        if (qmm_chain_end(ctx->dev->qmm)) {
+            GGML_LOG_ERROR("MI355X graph_compute: %s\n", qmm_last_error());
+            return GGML_STATUS_FAILED;
+        }
+    }
+    if (timing && ctx->ev_t0 && ctx->ev_t1) qmm_event_record(ctx->dev->qmm, ctx->ev_t1, qmm_stream(ctx->dev->qmm));
     // the scheduler reads results right after graph_compute/synchronize; a bad expert id surfaces here
     if (qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm))) {
         GGML_LOG_ERROR("MI355X graph_compute: %s\n", qmm_last_error());
         return GGML_STATUS_FAILED;
+    }
+    if (timing && ctx->ev_t0 && ctx->ev_t1) {
+        float ms = 0.0f;
+        int64_t n_tok = 1;                                   // tokens of the ubatch = ne[1] of the widest 2-D activation in the graph
+        for (int i = 0; i < n_nodes; ++i)
+            if (cgraph->nodes[i]->op == GGML_OP_MUL_MAT && cgraph->nodes[i]->ne[2] == 1) n_tok = std::max<int64_t>(n_tok, cgraph->nodes[i]->ne[1]);
+        if (!qmm_event_elapsed_ms(ctx->dev->qmm, ctx->ev_t0, ctx->ev_t1, &ms)) {
+            if (n_tok == 1) { ctx->ms_tg += ms; ctx->graphs_tg++; }
+            else { ctx->ms_pp += ms; ctx->graphs_pp++; ctx->tokens_pp += n_tok; }
+        }
     }
     return GGML_STATUS_SUCCESS;
 }

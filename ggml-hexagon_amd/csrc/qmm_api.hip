@@ -441,6 +441,22 @@ qmm_event * qmm_event_create(qmm_ctx * c) {
     }
     return e;
 }
+qmm_event * qmm_event_create_timing(qmm_ctx * c) {
+    if (!c || hipSetDevice(c->device) != hipSuccess) { fail(QMM_EINVAL, "qmm_event_create_timing: bad ctx"); return nullptr; }
+    qmm_event * e = new qmm_event;
+    if (hipEventCreate(&e->ev) != hipSuccess) {
+        fail(QMM_EHIP, "qmm_event_create_timing: hipEventCreate failed");
+        delete e;
+        return nullptr;
+    }
+    return e;
+}
+int qmm_event_elapsed_ms(qmm_ctx * c, qmm_event * e0, qmm_event * e1, float * ms) {
+    if (!c || !e0 || !e1 || !ms) return fail(QMM_EINVAL, "qmm_event_elapsed_ms: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventElapsedTime(ms, e0->ev, e1->ev));
+    return QMM_OK;
+}
 void qmm_event_destroy(qmm_ctx * c, qmm_event * e) {
     if (!e) return;
     if (c) (void) hipSetDevice(c->device);

@@ -109,6 +109,8 @@ typedef struct qmm_event qmm_event;
 QMM_API int          qmm_memcpy2d_d2d(qmm_ctx * ctx, void * dst, size_t dpitch, const void * src, size_t spitch,
                                       size_t width, size_t height, void * stream);
 QMM_API qmm_event *  qmm_event_create(qmm_ctx * ctx);
+QMM_API qmm_event *  qmm_event_create_timing(qmm_ctx * ctx);                             /* an event pair of these can be timed */
+QMM_API int          qmm_event_elapsed_ms(qmm_ctx * ctx, qmm_event * start, qmm_event * end, float * ms);   /* both recorded and complete */
 QMM_API void         qmm_event_destroy(qmm_ctx * ctx, qmm_event * ev);
 QMM_API int          qmm_event_record(qmm_ctx * ctx, qmm_event * ev, void * stream);
 QMM_API int          qmm_stream_wait_event(qmm_ctx * ctx, void * stream, qmm_event * ev);

@@ -1,0 +1,133 @@
+"""Every BASELINE config's REAL matrix shapes through the HIP path, on the driver's box.
+
+For each (type, K, M) a recipe of BASELINE.json's configs puts in a model (src/llama-quant.cpp:129-131, 166-168,
+235-255, 291-322) the C-ABI result is compared with the CPU oracle on SAMPLED weight rows (the oracle is scalar C: whole matrices
+would take minutes), at N = 1 and 8 (mat-vec kernels, Q8-exact: max|err|/rms <= 2e-5) and N = 512 (MFMA path, default F16_Q8 mode:
+rel-L2 <= 1e-3 AND max|err|/rms, printed and bounded: the per-element bar of the north-star).  MUL_MAT_ID runs at Mixtral's size
+(8 experts of 14336 x 4096 and 4096 x 14336 Q4_K, 2 used).  Size-independent properties (determinism, exact homogeneity) ride along.
+The reference's own bar for all of these is NMSE <= 5e-4 (tests/test-backend-ops.cpp:1982-1984, 2075-2077).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle.pyoracle import ACT_REF, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, TYPE_NAMES  # noqa: E402
+
+# (config, type, K, M): the distinct quantized MUL_MAT shapes of BASELINE.json's configs
+SHAPES = [
+    ("llama2-7b-q4_0", Q4_0, 4096, 4096), ("llama2-7b-q4_0", Q4_0, 4096, 11008), ("llama2-7b-q4_0", Q4_0, 11008, 4096),
+    ("llama2-7b-q4_0", Q6_K, 4096, 32000),
+    ("llama3-8b-q4_k_m", Q4_K, 4096, 4096), ("llama3-8b-q4_k_m", Q4_K, 4096, 1024), ("llama3-8b-q4_k_m", Q6_K, 4096, 1024),
+    ("llama3-8b-q4_k_m", Q4_K, 4096, 14336), ("llama3-8b-q4_k_m", Q4_K, 14336, 4096), ("llama3-8b-q4_k_m", Q6_K, 14336, 4096),
+    ("llama3-8b-q4_k_m", Q6_K, 4096, 128256),
+    ("llama3-70b-q4_k_m", Q4_K, 8192, 8192), ("llama3-70b-q4_k_m", Q5_K, 8192, 1024), ("llama3-70b-q4_k_m", Q6_K, 8192, 1024),
+    ("llama3-70b-q4_k_m", Q4_K, 8192, 28672), ("llama3-70b-q4_k_m", Q4_K, 28672, 8192), ("llama3-70b-q4_k_m", Q6_K, 28672, 8192),
+    ("llama3-70b-q4_k_m", Q6_K, 8192, 128256),
+    ("mixtral-8x7b-q4_k_m", Q8_0, 4096, 1024), ("mixtral-8x7b-q4_k_m", Q5_K, 4096, 4096), ("mixtral-8x7b-q4_k_m", Q6_K, 4096, 32000),
+]
+IDS = [f"{c}:{TYPE_NAMES[t]}-{k}x{m}" for c, t, k, m in SHAPES]
+
+
+@pytest.fixture(scope="module")
+def qmm():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ggml_hexagon_amd.capi import Qmm
+    q = Qmm(0)
+    yield q
+    q.close()
+
+
+def max_over_rms(got, want):
+    want = want.astype(np.float64)
+    return float(np.max(np.abs(got - want)) / max(np.sqrt(np.mean(want ** 2)), 1e-30))
+
+
+def rel_l2(got, want):
+    want = want.astype(np.float64)
+    return float(np.sqrt(np.sum((got - want) ** 2) / max(np.sum(want ** 2), 1e-30)))
+
+
+REPORT = []
+
+
+@pytest.mark.parametrize("cfg,t,k,m", SHAPES, ids=IDS)
+def test_config_shape_against_oracle(qmm, oracle, cfg, t, k, m):
+    import ggml_hexagon_amd.synth as synth
+    dev = torch.device("cuda", 0)
+    w = synth.synth_weights_torch(t, m, k, dev, seed=k + m + t)
+    g = torch.Generator(device=dev).manual_seed(m)
+    rng = np.random.default_rng(k)
+    rows = np.sort(rng.choice(m, 48, replace=False))
+    w_rows = w[torch.from_numpy(rows).to(dev)].cpu().numpy()
+    for n in (1, 8, 512):
+        x = torch.rand((n, k), device=dev, generator=g) * 2 - 1
+        y = qmm.mul_mat(t, w, k, x)
+        xs = x.cpu().numpy()
+        toks = np.arange(n) if n <= 8 else np.sort(rng.choice(n, 96, replace=False))        # 48 rows x 96 tokens at N = 512
+        want = oracle.mul_mat(t, w_rows, k, xs[toks], ACT_REF)
+        got = y.cpu().numpy()[np.ix_(toks, rows)]
+        mr, l2 = max_over_rms(got, want), rel_l2(got, want)
+        REPORT.append((cfg, TYPE_NAMES[t], k, m, n, mr, l2))
+        if n <= 8:
+            assert mr <= 2e-5, (cfg, TYPE_NAMES[t], k, m, n, mr)
+        else:
+            # F16_Q8 prefill: the same int8 activations as the CPU, weights and activations rounded to f16 for the MFMA.  rel-L2 is the
+            # round-1 bar; the per-element figure is what "1e-3 rel on the f32 accumulator" asks about: 16k samples of an error whose
+            # rms is 3-5e-4 of the output rms peak at ~4 sigma, so the maximum sits at 1.5-2.5e-3
+            assert l2 <= 1e-3, (cfg, TYPE_NAMES[t], k, m, n, l2)
+            assert mr <= 4e-3, (cfg, TYPE_NAMES[t], k, m, n, mr)
+        assert torch.equal(y, qmm.mul_mat(t, w, k, x))                                       # deterministic
+        if n == 1:
+            assert torch.equal(qmm.mul_mat(t, w, k, x * 0.5), y * 0.5)                       # exact homogeneity (power of two)
+    del w
+    torch.cuda.empty_cache()
+
+
+def test_zz_print_report():
+    """not a check: the measured figures of the run, for GPUTEST logs and DESIGN.md"""
+    print("\nconfig type K M N max|err|/rms rel-L2")
+    for r in REPORT:
+        print("%s %s %d %d %d %.2e %.2e" % r)
+    pp = [r for r in REPORT if r[4] == 512]
+    if pp:
+        print("MFMA path over %d shapes: max|err|/rms worst %.2e, rel-L2 worst %.2e" % (len(pp), max(r[5] for r in pp), max(r[6] for r in pp)))
+
+
+@pytest.mark.parametrize("k,m", [(4096, 14336), (14336, 4096)], ids=["ffn_gate_up_exps", "ffn_down_exps"])
+@pytest.mark.parametrize("n_tokens", [1, 512])
+def test_mul_mat_id_at_mixtral_size(qmm, oracle, k, m, n_tokens):
+    """ffn_{gate,up}_exps [4096, 14336, 8] and ffn_down_exps [14336, 4096, 8], Q4_K, 2 of 8 experts per token
+    (src/llama-graph.cpp:870-894); ids = per-token shuffle of the experts, first two taken (tests/test-backend-ops.cpp:2113-2132)"""
+    import ggml_hexagon_amd.synth as synth
+    dev = torch.device("cuda", 0)
+    n_expert, n_used, t = 8, 2, Q4_K
+    w = synth.synth_weights_torch(t, n_expert * m, k, dev, seed=k).reshape(n_expert, m, -1)
+    g = torch.Generator(device=dev).manual_seed(n_tokens)
+    rng = np.random.default_rng(m)
+    ids_full = torch.stack([torch.randperm(n_expert, device=dev, generator=g) for _ in range(n_tokens)]).to(torch.int32)
+    ne11 = n_used if k == 14336 else 1                       # ffn_down reads one row per used expert, gate/up share the token's row
+    b = torch.rand((n_tokens, ne11, k), device=dev, generator=g) * 2 - 1
+    y = qmm.mul_mat_id(t, w, k, b, ids_full[:, :n_used])
+    qmm.synchronize()
+    rows = np.sort(rng.choice(m, 32, replace=False))
+    toks = np.arange(n_tokens) if n_tokens <= 8 else np.sort(rng.choice(n_tokens, 64, replace=False))
+    w_rows = w[:, torch.from_numpy(rows).to(dev), :].cpu().numpy()
+    want = oracle.mul_mat_id(t, w_rows, k, len(rows), b.cpu().numpy()[toks], ids_full.cpu().numpy()[toks][:, :n_used], ACT_REF)
+    got = y.cpu().numpy()[toks][:, :, rows]
+    mr, l2 = max_over_rms(got, want), rel_l2(got, want)
+    print(f"\nMUL_MAT_ID {k}x{m} N={n_tokens}: max|err|/rms {mr:.2e} rel-L2 {l2:.2e}")
+    if n_tokens * n_used <= 16:
+        assert mr <= 2e-5, mr
+    else:
+        assert l2 <= 1e-3 and mr <= 4e-3, (l2, mr)
+    assert torch.equal(y, qmm.mul_mat_id(t, w, k, b, ids_full[:, :n_used]))
+    # the paired launch (ffn_gate_exps + ffn_up_exps share b and ids) at full size equals two single calls
+    if k == 4096:
+        w2 = synth.synth_weights_torch(t, n_expert * m, k, dev, seed=k + 1).reshape(n_expert, m, -1)
+        o0, o1 = torch.empty_like(y), torch.empty_like(y)
+        qmm.mul_mat_id_pair(t, w, w2, k, b, ids_full[:, :n_used], o0, o1)
+        assert torch.equal(o0, y) and torch.equal(o1, qmm.mul_mat_id(t, w2, k, b, ids_full[:, :n_used]))
+    qmm.synchronize()
