@@ -8,6 +8,7 @@ import ctypes as C
 from . import build as _build
 
 Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 2, 8, 12, 13, 14, 15
+Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL = 3, 6, 7, 10, 11, 20
 ACT_REF, ACT_X86 = 0, 1
 PREC_BF16, PREC_F16_Q8 = 0, 1
 MATVEC_MAX_N = 8
@@ -198,10 +199,12 @@ class Qmm:
     def quantize_act(self, vec_dot_type, x):
         import torch
         rows, k = x.shape
-        qb = 32 if vec_dot_type == Q8_0 else 256
+        qb = 256 if vec_dot_type == Q8_K else 32
         q = torch.empty((rows, k), dtype=torch.int8, device=x.device)
         d = torch.empty((rows, k // qb), dtype=torch.float32, device=x.device)
         bs = torch.zeros((rows, k // 16), dtype=torch.int16, device=x.device) if vec_dot_type == Q8_K else None
+        if vec_dot_type == 9:               # Q8_1: the third array is s = f16(d * sum(q)) per block, as f32
+            bs = torch.zeros((rows, k // 32), dtype=torch.float32, device=x.device)
         self._chk(self.lib.qmm_quantize_act(self.ctx, vec_dot_type, x.data_ptr(), rows, k, x.stride(0), q.data_ptr(),
                                             d.data_ptr(), bs.data_ptr() if bs is not None else None, self._stream()))
         return q, d, bs

@@ -112,7 +112,10 @@ ggml_backend_device    g_devices[GGML_MI355X_MAX_DEVICES];
 int                    g_ndev = 0;
 
 bool type_supported(enum ggml_type t) {
-    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K;
+    // the north-star's five formats plus SURVEY 8f-4's (round 2): any stock Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K_* / IQ4_NL GGUF keeps its
+    // matmul weights on the device; the kernel library answers the same question through qmm_row_size() != 0
+    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K ||
+           t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_IQ4_NL;
 }
 
 // ----------------------------------------------------------------------------------------------- buffer

@@ -13,14 +13,9 @@ using namespace qmm;
 
 namespace {
 
-bool type_ok(int t) { return t == T_Q4_0 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K; }
-int  blck(int t) { return (t == T_Q4_0 || t == T_Q8_0) ? 32 : 256; }
-int  tsize(int t) {
-    switch (t) {
-        case T_Q4_0: return 18; case T_Q8_0: return 34; case T_Q4_K: return 144; case T_Q5_K: return 176;
-        case T_Q6_K: return 210; default: return 0;
-    }
-}
+bool type_ok(int t) { return type_known(t); }
+int  blck(int t) { return type_blck(t); }
+int  tsize(int t) { return type_tsize(t); }
 
 } // namespace
 
@@ -103,13 +98,9 @@ static int launch_matvec(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, con
 }
 
 static int matvec_any(qmm_ctx * c, hipStream_t st, int type, const MatvecGroup & g, const float * x, int64_t ldx, int K, int N) {
-    switch (type) {
-        case T_Q4_0: return launch_matvec<T_Q4_0>(c, st, g, x, ldx, K, N);
-        case T_Q8_0: return launch_matvec<T_Q8_0>(c, st, g, x, ldx, K, N);
-        case T_Q4_K: return launch_matvec<T_Q4_K>(c, st, g, x, ldx, K, N);
-        case T_Q5_K: return launch_matvec<T_Q5_K>(c, st, g, x, ldx, K, N);
-        default:     return launch_matvec<T_Q6_K>(c, st, g, x, ldx, K, N);
-    }
+#define QMM_X(TT) return launch_matvec<TT>(c, st, g, x, ldx, K, N)
+    QMM_FOR_TYPE(type, QMM_X)
+#undef QMM_X
 }
 
 static int check_mm(int type, const void * w, int64_t rb, int64_t K, const float * x, int64_t ldx, const char * who) {
@@ -195,6 +186,7 @@ static int chain_record(qmm_ctx * c, hipStream_t st, const qmm_weight * ws, int 
     int64_t rows = 0;
     for (int i = 0; i < nw; ++i) {
         if (ws[i].M <= 0) return 0;
+        if (ws[i].type != T_Q4_0 && ws[i].type != T_Q8_0 && ws[i].type != T_Q4_K && ws[i].type != T_Q5_K && ws[i].type != T_Q6_K) return 0;
         const bool kq = ws[i].type == T_Q4_K || ws[i].type == T_Q5_K || ws[i].type == T_Q6_K;
         fams[kq ? 1 : 0]++;
         rows += ws[i].M;
@@ -521,21 +513,18 @@ int qmm_dequantize(qmm_ctx * c, int type, const void * w, int64_t rb, int64_t ro
     HIP_TRY(hipSetDevice(c->device));
     QMM_CHAIN_FLUSH(c);
     hipStream_t s = c->s(st);
-    switch (type) {
-        case T_Q4_0: return launch_dequant<T_Q4_0>(s, w, rb, rows, K, dst);
-        case T_Q8_0: return launch_dequant<T_Q8_0>(s, w, rb, rows, K, dst);
-        case T_Q4_K: return launch_dequant<T_Q4_K>(s, w, rb, rows, K, dst);
-        case T_Q5_K: return launch_dequant<T_Q5_K>(s, w, rb, rows, K, dst);
-        default:     return launch_dequant<T_Q6_K>(s, w, rb, rows, K, dst);
-    }
+#define QMM_X(TT) return launch_dequant<TT>(s, w, rb, rows, K, dst)
+    QMM_FOR_TYPE(type, QMM_X)
+#undef QMM_X
 }
 
 // ------------------------------------------------------------------------------------------- quantize_act
 
 int qmm_quantize_act(qmm_ctx * c, int vt, const float * x, int64_t rows, int64_t K, int64_t ldx,
                      int8_t * q, float * d, int16_t * bs, void * st) {
-    if (!c || (vt != T_Q8_0 && vt != T_Q8_K)) return fail(QMM_EINVAL, "qmm_quantize_act: vec_dot_type %d", vt);
-    if (K <= 0 || K % (vt == T_Q8_0 ? 32 : 256) || ldx % 4 || (uintptr_t) x % 16 || (uintptr_t) q % 4)
+    if (!c || (vt != T_Q8_0 && vt != T_Q8_1 && vt != T_Q8_K)) return fail(QMM_EINVAL, "qmm_quantize_act: vec_dot_type %d", vt);
+    if (vt == T_Q8_1 && (!bs || (uintptr_t) bs % 4)) return fail(QMM_EINVAL, "qmm_quantize_act: Q8_1 wants the s array (f32 [rows, K/32]) in `bs`");
+    if (K <= 0 || K % (vt == T_Q8_K ? 256 : 32) || ldx % 4 || (uintptr_t) x % 16 || (uintptr_t) q % 4)
         return fail(QMM_EINVAL, "qmm_quantize_act: K/ldx/alignment");
     if (rows == 0) return QMM_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -544,6 +533,8 @@ int qmm_quantize_act(qmm_ctx * c, int vt, const float * x, int64_t rows, int64_t
     dim3 grid((unsigned) ((rows + rpb - 1) / rpb));
     if (vt == T_Q8_0)
         hipLaunchKernelGGL((quantize_act_kernel<T_Q8_0>), grid, dim3(256), 0, c->s(st), x, ldx, (int) rows, (int) K, c->act_mode, q, d, bs, rpb);
+    else if (vt == T_Q8_1)
+        hipLaunchKernelGGL((quantize_act_kernel<T_Q8_1>), grid, dim3(256), 0, c->s(st), x, ldx, (int) rows, (int) K, c->act_mode, q, d, bs, rpb);
     else
         hipLaunchKernelGGL((quantize_act_kernel<T_Q8_K>), grid, dim3(256), 0, c->s(st), x, ldx, (int) rows, (int) K, c->act_mode, q, d, bs, rpb);
     HIP_TRY(hipGetLastError());

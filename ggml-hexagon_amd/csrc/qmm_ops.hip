@@ -1224,8 +1224,8 @@ attn_prefill_kernel(const AttnArgs g, const int N) {
 
 bool is_binary(int op) { return op >= QMM_OP_ADD && op <= QMM_OP_DIV; }
 bool is_unary(int op) { return op >= QMM_OP_SCALE && op <= QMM_OP_EXP; }
-bool quant_type(int t) { return t == T_Q4_0 || t == T_Q8_0 || t == T_Q4_K || t == T_Q5_K || t == T_Q6_K; }
-int  quant_blck(int t) { return t == T_Q4_0 || t == T_Q8_0 ? 32 : 256; }
+bool quant_type(int t) { return type_known(t); }
+int  quant_blck(int t) { return type_blck(t); }
 
 bool sup_binary(const qmm_tensor * a, const qmm_tensor * b, const qmm_tensor * d) {
     if (!a || !b || !d || a->type != G_F32 || b->type != G_F32 || d->type != G_F32) return false;
@@ -1538,11 +1538,11 @@ int qmm_op_compute(qmm_ctx * ctx, int op, const qmm_tensor * a, const qmm_tensor
                                                (char *) d->data, shape_of(a), shape_of(b), shape_of(d)); break;
                 case G_F16: hipLaunchKernelGGL((get_rows_kernel<__half>), grid, dim3(256), 0, st, (const char *) a->data, (const char *) b->data,
                                                (char *) d->data, shape_of(a), shape_of(b), shape_of(d)); break;
-                case T_Q4_0: return launch_get_rows_q<T_Q4_0>(st, a, b, d);
-                case T_Q8_0: return launch_get_rows_q<T_Q8_0>(st, a, b, d);
-                case T_Q4_K: return launch_get_rows_q<T_Q4_K>(st, a, b, d);
-                case T_Q5_K: return launch_get_rows_q<T_Q5_K>(st, a, b, d);
-                default:     return launch_get_rows_q<T_Q6_K>(st, a, b, d);
+                default: {
+#define QMM_X(TT) return launch_get_rows_q<TT>(st, a, b, d)
+                    QMM_FOR_TYPE(a->type, QMM_X)
+#undef QMM_X
+                }
             }
             HIP_TRY(hipGetLastError());
             return QMM_OK;

@@ -11,9 +11,11 @@ from __future__ import annotations
 import numpy as np
 
 Q4_0, Q8_0, Q4_K, Q5_K, Q6_K = 2, 8, 12, 13, 14
-BLCK = {Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256}
-TYPE_SIZE = {Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210}
-NAMES = {Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K"}
+Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL = 3, 6, 7, 10, 11, 20      # ggml-common.h:174-207, 253-277, 405-410
+BLCK = {Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q2_K: 256, Q3_K: 256, IQ4_NL: 32}
+TYPE_SIZE = {Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q2_K: 84, Q3_K: 110, IQ4_NL: 18}
+NAMES = {Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K",
+         Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q2_K: "q2_K", Q3_K: "q3_K", IQ4_NL: "iq4_nl"}
 BY_NAME = {v: k for k, v in NAMES.items()}
 
 
@@ -44,9 +46,25 @@ def synth_weights(t: int, rows: int, k: int, seed: int = 0, sigma: float = 0.02)
         blk[:, 2:4] = _f16_bytes(rng, nb, 3 * sigma / 40, signed=False)          # dmin (offset ~ dmin*m)
     elif t == Q6_K:
         blk[:, 208:210] = _f16_bytes(rng, nb, 3 * sigma / 32 / 80)
+    elif t in (Q4_1, Q5_1):                                   # w = q*d + m, q in [0, 15 | 31]
+        blk[:, 0:2] = _f16_bytes(rng, nb, 6 * sigma / (15 if t == Q4_1 else 31), signed=False)
+        blk[:, 2:4] = (-_f16_val(rng, nb, 3 * sigma)).astype(np.float16).view(np.uint8).reshape(nb, 2)
+    elif t == Q5_0:
+        blk[:, 0:2] = _f16_bytes(rng, nb, 3 * sigma / 16)
+    elif t == IQ4_NL:
+        blk[:, 0:2] = _f16_bytes(rng, nb, 3 * sigma / 127)
+    elif t == Q2_K:                                           # w = d*(sc&15)*q - dmin*(sc>>4), q <= 3
+        blk[:, 80:82] = _f16_bytes(rng, nb, 6 * sigma / 3 / 10, signed=False)
+        blk[:, 82:84] = _f16_bytes(rng, nb, 3 * sigma / 10, signed=False)
+    elif t == Q3_K:                                           # w = d*(sc-32)*(q-4 .. q)
+        blk[:, 108:110] = _f16_bytes(rng, nb, 3 * sigma / 4 / 20)
     else:
         raise ValueError(t)
     return blk.reshape(rows, -1)
+
+
+def _f16_val(rng, n, scale):
+    return rng.uniform(0.5, 1.5, n).astype(np.float32) * scale
 
 
 def synth_weights_torch(t: int, rows: int, k: int, device, seed: int = 0, sigma: float = 0.02):
@@ -73,6 +91,18 @@ def synth_weights_torch(t: int, rows: int, k: int, device, seed: int = 0, sigma:
         blk[:, 2:4] = f16(3 * sigma / 40, signed=False)
     elif t == Q6_K:
         blk[:, 208:210] = f16(3 * sigma / 32 / 80)
+    elif t in (Q4_1, Q5_1):
+        blk[:, 0:2] = f16(6 * sigma / (15 if t == Q4_1 else 31), signed=False)
+        blk[:, 2:4] = (-(torch.rand(nb, device=device, generator=g) + 0.5) * 3 * sigma).to(torch.float16).view(torch.uint8).reshape(nb, 2)
+    elif t == Q5_0:
+        blk[:, 0:2] = f16(3 * sigma / 16)
+    elif t == IQ4_NL:
+        blk[:, 0:2] = f16(3 * sigma / 127)
+    elif t == Q2_K:
+        blk[:, 80:82] = f16(6 * sigma / 3 / 10, signed=False)
+        blk[:, 82:84] = f16(3 * sigma / 10, signed=False)
+    elif t == Q3_K:
+        blk[:, 108:110] = f16(3 * sigma / 4 / 20)
     else:
         raise ValueError(t)
     return blk.reshape(rows, -1)

@@ -25,7 +25,8 @@
  *   - `stream` is a hipStream_t passed as void* and used verbatim (NULL = HIP's default stream);
  *     qmm_stream() returns a non-blocking stream owned by the context for callers that want one.
  *     Calls are asynchronous on that stream; nothing synchronizes except qmm_synchronize / qmm_memcpy_h2d/_d2h;
- *   - `type` is ggml's enum ggml_type value: Q4_0=2, Q8_0=8, Q4_K=12, Q5_K=13, Q6_K=14;
+ *   - `type` is ggml's enum ggml_type value: Q4_0=2, Q8_0=8, Q4_K=12, Q5_K=13, Q6_K=14 (the north-star's five) and, SURVEY 8f-4,
+ *     Q4_1=3, Q5_0=6, Q5_1=7, Q2_K=10, Q3_K=11, IQ4_NL=20 (ggml/src/ggml-common.h:174-207, 253-277, 405-410);
  *   - weights are in GGUF wire layout: rows of blocks, `w_row_bytes` apart (>= K/blck*type_size);
  *   - returns 0 on success, a negative QMM_E* code otherwise (qmm_last_error() has the text, per thread).
  *     Nothing falls back to the CPU;
@@ -125,8 +126,9 @@ QMM_API int qmm_dequantize(qmm_ctx * ctx, int type, const void * w, int64_t w_ro
 /* Activation quantizer in the device layout the kernels use (structure of arrays):
  *   q  int8  [rows, K]
  *   d  f32   [rows, K/32]   for Q8_0 (the fp16-rounded scale, widened)   | [rows, K/256] for Q8_K
- *   bs int16 [rows, K/16]   Q8_K only (may be NULL)
- * `vec_dot_type` is 8 (Q8_0) or 15 (Q8_K).  x rows are ldx floats apart. */
+ *   bs int16 [rows, K/16]   Q8_K only (may be NULL); for Q8_1 this argument is the f32 array s [rows, K/32]:
+ *                           block_q8_1's s = f16(d * sum of the block's int8), widened (ggml-quants.c:220-252)
+ * `vec_dot_type` is 8 (Q8_0), 9 (Q8_1) or 15 (Q8_K).  x rows are ldx floats apart. */
 QMM_API int qmm_quantize_act(qmm_ctx * ctx, int vec_dot_type, const float * x, int64_t rows, int64_t K,
                              int64_t ldx, int8_t * q, float * d, int16_t * bs, void * stream);
 

@@ -20,7 +20,15 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 
 Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 2, 8, 12, 13, 14, 15
-TYPE_NAMES = {Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K"}
+Q4_1, Q5_0, Q5_1, Q8_1, Q2_K, Q3_K, IQ4_NL = 3, 6, 7, 9, 10, 11, 20
+TYPE_NAMES = {Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K",
+              Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_1: "q8_1", Q2_K: "q2_K", Q3_K: "q3_K", IQ4_NL: "iq4_nl"}
+WEIGHT_TYPES = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL)
+
+
+def vec_dot_type(t: int) -> int:
+    """type_traits_cpu[t].vec_dot_type (ggml/src/ggml-cpu/ggml-cpu.c:256-…)"""
+    return Q8_1 if t in (Q4_1, Q5_1) else Q8_0 if t in (Q4_0, Q8_0, Q5_0, IQ4_NL) else Q8_K
 ACT_REF, ACT_X86 = 0, 1
 
 
@@ -51,6 +59,7 @@ class Oracle:
         L.qmo_fp32_to_fp16.argtypes = [C.c_float]
         L.qmo_dequantize_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
         L.qmo_quantize_row_q8_0.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        L.qmo_quantize_row_q8_1.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.qmo_quantize_row_q8_K.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.qmo_vec_dot.restype = C.c_float
         L.qmo_vec_dot.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
@@ -80,6 +89,8 @@ class Oracle:
         for r in range(rows):
             if vt == Q8_0:
                 self.lib.qmo_quantize_row_q8_0(_ptr(x[r]), _ptr(out[r]), k, act_mode)
+            elif vt == Q8_1:
+                self.lib.qmo_quantize_row_q8_1(_ptr(x[r]), _ptr(out[r]), k, act_mode)
             else:
                 self.lib.qmo_quantize_row_q8_K(_ptr(x[r]), _ptr(out[r]), k)
         return out
@@ -172,7 +183,7 @@ class RefGgml:
         """impl='cpu': ggml-cpu's SIMD quantize_row_q8_0/q8_K; impl='ref': ggml-base's *_ref"""
         x = np.ascontiguousarray(x, np.float32)
         rows, k = x.shape
-        vt = Q8_0 if t in (Q4_0, Q8_0) else Q8_K
+        vt = vec_dot_type(t)
         out = np.zeros((rows, self.row_size(vt, k)), np.uint8)
         if impl == "cpu":
             fn = getattr(self.cpu, f"quantize_row_{TYPE_NAMES[vt]}")
@@ -184,7 +195,7 @@ class RefGgml:
         return out
 
     def vec_dot(self, t, k, w_row: np.ndarray, a_row: np.ndarray) -> float:
-        vt = "q8_0" if t in (Q4_0, Q8_0) else "q8_K"
+        vt = TYPE_NAMES[vec_dot_type(t)]
         fn = getattr(self.cpu, f"ggml_vec_dot_{TYPE_NAMES[t]}_{vt}")
         fn.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
         out = C.c_float(0)
@@ -196,7 +207,7 @@ class RefGgml:
         ggml_compute_forward_mul_mat): dst f32 [N, M]"""
         w = np.ascontiguousarray(w, np.uint8).reshape(-1, self.row_size(t, k))
         acts = self.quantize_act(t, x)
-        vt = "q8_0" if t in (Q4_0, Q8_0) else "q8_K"
+        vt = TYPE_NAMES[vec_dot_type(t)]
         fn = getattr(self.cpu, f"ggml_vec_dot_{TYPE_NAMES[t]}_{vt}")
         fn.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
         n, m = acts.shape[0], w.shape[0]

@@ -19,8 +19,8 @@
 
 int qmo_blck_size(int type) {
     switch (type) {
-        case QMO_Q4_0: case QMO_Q8_0: return 32;
-        case QMO_Q4_K: case QMO_Q5_K: case QMO_Q6_K: case QMO_Q8_K: return 256;
+        case QMO_Q4_0: case QMO_Q8_0: case QMO_Q4_1: case QMO_Q5_0: case QMO_Q5_1: case QMO_Q8_1: case QMO_IQ4_NL: return 32;
+        case QMO_Q2_K: case QMO_Q3_K: case QMO_Q4_K: case QMO_Q5_K: case QMO_Q6_K: case QMO_Q8_K: return 256;
         default: return 0;
     }
 }
@@ -29,6 +29,13 @@ size_t qmo_type_size(int type) {
     switch (type) {
         case QMO_Q4_0: return 18;   /* f16 d, 16 nibble bytes                       ggml-common.h:167-172 */
         case QMO_Q8_0: return 34;   /* f16 d, 32 int8                               ggml-common.h:209-214 */
+        case QMO_Q4_1: return 20;   /* f16 d, f16 m, 16 nibble bytes                ggml-common.h:174-185 */
+        case QMO_Q5_0: return 22;   /* f16 d, 4 high-bit bytes, 16 nibble bytes     ggml-common.h:187-193 */
+        case QMO_Q5_1: return 24;   /* f16 d, f16 m, 4 high-bit bytes, 16 nibbles   ggml-common.h:195-207 */
+        case QMO_Q8_1: return 36;   /* f16 d, f16 s = d * sum(qs), 32 int8          ggml-common.h:216-227 */
+        case QMO_IQ4_NL: return 18; /* f16 d, 16 bytes of indices into kvalues_iq4nl ggml-common.h:405-410 */
+        case QMO_Q2_K: return 84;   /* 16 scale|min nibbles, 64 2-bit bytes, f16 d, f16 dmin  ggml-common.h:253-265 */
+        case QMO_Q3_K: return 110;  /* 32 hmask, 64 2-bit bytes, 12 scale bytes, f16 d        ggml-common.h:271-277 */
         case QMO_Q4_K: return 144;  /* f16 d, f16 dmin, 12 scale bytes, 128 nibbles ggml-common.h:285-296 */
         case QMO_Q5_K: return 176;  /* + 32 high-bit bytes before the nibbles       ggml-common.h:298-314 */
         case QMO_Q6_K: return 210;  /* 128 ql, 64 qh, 16 int8 scales, f16 d         ggml-common.h:316-326 */
@@ -44,8 +51,9 @@ size_t qmo_row_size(int type, int64_t k) {
 
 int qmo_vec_dot_type(int type) {   /* type_traits_cpu[].vec_dot_type, ggml-cpu.c:256-… */
     switch (type) {
-        case QMO_Q4_0: case QMO_Q8_0: return QMO_Q8_0;
-        case QMO_Q4_K: case QMO_Q5_K: case QMO_Q6_K: return QMO_Q8_K;
+        case QMO_Q4_0: case QMO_Q8_0: case QMO_Q5_0: case QMO_IQ4_NL: return QMO_Q8_0;
+        case QMO_Q4_1: case QMO_Q5_1: return QMO_Q8_1;
+        case QMO_Q2_K: case QMO_Q3_K: case QMO_Q4_K: case QMO_Q5_K: case QMO_Q6_K: return QMO_Q8_K;
         default: return -1;
     }
 }
@@ -105,11 +113,21 @@ static inline void k4_scale_min(int j, const uint8_t *s, int *sc, int *mn) {
     }
 }
 
+/* Q3_K: sixteen 6-bit scales out of 12 bytes, as the reference's aux[] shuffle leaves them (ggml-quants.c:1074-1079):
+ * scale j = low nibble (j < 8: of byte j, else high nibble of byte j - 8) | two bits of byte 8 + j % 4 (pair j / 4) << 4 */
+static inline int q3k_scale(const uint8_t *s, int j) {
+    const int lo = j < 8 ? (s[j] & 15) : (s[j - 8] >> 4);
+    const int hi = (s[8 + (j & 3)] >> (2 * (j >> 2))) & 3;
+    return (lo | (hi << 4)) - 32;
+}
+
+static const int8_t iq4nl_values[16] = { -127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113 };   /* ggml-common.h kvalues_iq4nl */
+
 /* ---------------------------------------------------------------- block unpack */
 
 int qmo_dequantize_row(int type, const void *src, float *dst, int64_t k) {
     const int bs = qmo_blck_size(type);
-    if (!bs || type == QMO_Q8_K || k % bs) return -1;
+    if (!bs || type == QMO_Q8_K || type == QMO_Q8_1 || k % bs) return -1;
     const size_t ts = qmo_type_size(type);
     const int64_t nb = k / bs;
     const uint8_t *blk = (const uint8_t *)src;
@@ -128,6 +146,56 @@ int qmo_dequantize_row(int type, const void *src, float *dst, int64_t k) {
             const float d = rd_f16(blk);
             const int8_t *qs = (const int8_t *)(blk + 2);
             for (int j = 0; j < 32; ++j) dst[j] = (float)qs[j] * d;
+        } break;
+        case QMO_Q4_1: {                                  /* ggml-quants.c:275-294: x*d + m */
+            const float d = rd_f16(blk), m = rd_f16(blk + 2);
+            const uint8_t *qs = blk + 4;
+            for (int j = 0; j < 16; ++j) {
+                dst[j]      = (float)(qs[j] & 15) * d + m;
+                dst[j + 16] = (float)(qs[j] >> 4) * d + m;
+            }
+        } break;
+        case QMO_Q5_0:                                    /* ggml-quants.c:296-320 */
+        case QMO_Q5_1: {                                  /* ggml-quants.c:322-347 */
+            const int one = type == QMO_Q5_1;
+            const float d = rd_f16(blk), m = one ? rd_f16(blk + 2) : 0.0f;
+            uint32_t qh; memcpy(&qh, blk + (one ? 4 : 2), 4);
+            const uint8_t *qs = blk + (one ? 8 : 6);
+            for (int j = 0; j < 16; ++j) {
+                const int x0 = (qs[j] & 15) | (int)(((qh >> j) & 1u) << 4);
+                const int x1 = (qs[j] >> 4) | (int)(((qh >> (j + 16)) & 1u) << 4);
+                if (one) { dst[j] = (float)x0 * d + m;        dst[j + 16] = (float)x1 * d + m; }
+                else     { dst[j] = (float)(x0 - 16) * d;     dst[j + 16] = (float)(x1 - 16) * d; }
+            }
+        } break;
+        case QMO_IQ4_NL: {                                /* ggml-quants.c:2436-2453 */
+            const float d = rd_f16(blk);
+            const uint8_t *qs = blk + 2;
+            for (int j = 0; j < 16; ++j) {
+                dst[j]      = d * (float)iq4nl_values[qs[j] & 15];
+                dst[j + 16] = d * (float)iq4nl_values[qs[j] >> 4];
+            }
+        } break;
+        case QMO_Q2_K: {                                  /* ggml-quants.c:712-745: 16 sub-blocks of 16, y = d*(sc&15)*q - dmin*(sc>>4) */
+            const uint8_t *sc = blk, *qs = blk + 16;
+            const float d = rd_f16(blk + 80), dmin = rd_f16(blk + 82);
+            for (int g = 0; g < 16; ++g) {                /* sub-block g: half n = g/8, shift 2*((g%8)/2), bytes 32n + 16*(g%2) .. +16 */
+                const float dl = d * (float)(sc[g] & 15), ml = dmin * (float)(sc[g] >> 4);
+                const uint8_t *q = qs + 32 * (g >> 3) + 16 * (g & 1);
+                const int shift = 2 * ((g & 7) >> 1);
+                for (int l = 0; l < 16; ++l) dst[16 * g + l] = dl * (float)((q[l] >> shift) & 3) - ml;
+            }
+        } break;
+        case QMO_Q3_K: {                                  /* ggml-quants.c:1056-1106: y = d*(sc-32)*(q2 - (hbit ? 0 : 4)) */
+            const uint8_t *hm = blk, *qs = blk + 32, *s12 = blk + 96;
+            const float d = rd_f16(blk + 108);
+            for (int g = 0; g < 16; ++g) {                /* same walk as Q2_K; the high bit of sub-block g is bit g/2 of hmask[16*(g%2) + l] */
+                const float dl = d * (float)q3k_scale(s12, g);
+                const uint8_t *q = qs + 32 * (g >> 3) + 16 * (g & 1), *h = hm + 16 * (g & 1);
+                const int shift = 2 * ((g & 7) >> 1), bit = g >> 1;
+                for (int l = 0; l < 16; ++l)
+                    dst[16 * g + l] = dl * (float)((int)((q[l] >> shift) & 3) - (((h[l] >> bit) & 1) ? 0 : 4));
+            }
         } break;
         case QMO_Q4_K:                                    /* ggml-quants.c:1280-1302 */
         case QMO_Q5_K: {                                  /* ggml-quants.c:1482-1508 */
@@ -199,6 +267,25 @@ void qmo_quantize_row_q8_0(const float *x, void *y, int64_t k, int act_mode) {
             const float id = d != 0.0f ? 1.0f / d : 0.0f;
             for (int j = 0; j < 32; ++j) qs[j] = (int8_t)roundf(x[j] * id);          /* ties away    */
         }
+    }
+}
+
+/* Q8_1: the bytes of Q8_0 plus s = f16(d * sum of the int8s), with the f32 d (ggml-quants.c:220-252; the AVX2 build multiplies the
+ * same f32 d by the integer sum, ggml-cpu-quants.c:1053-…: same value) */
+void qmo_quantize_row_q8_1(const float *x, void *y, int64_t k, int act_mode) {
+    uint8_t *out = (uint8_t *)y;
+    for (int64_t i = 0; i < k / 32; ++i, x += 32, out += 36) {
+        uint8_t tmp[34];
+        qmo_quantize_row_q8_0(x, tmp, 32, act_mode);
+        float amax = 0.0f;
+        for (int j = 0; j < 32; ++j) { const float a = fabsf(x[j]); if (a > amax) amax = a; }
+        const float d = amax / 127.0f;
+        int sum = 0;
+        for (int j = 0; j < 32; ++j) sum += (int8_t)tmp[2 + j];
+        const uint16_t sh = qmo_fp32_to_fp16((float)sum * d);
+        memcpy(out, tmp, 2);
+        memcpy(out + 2, &sh, 2);
+        memcpy(out + 4, tmp + 2, 32);
     }
 }
 
@@ -343,6 +430,86 @@ static float dot_q6_K(int64_t k, const uint8_t *w, const uint8_t *a) {   /* ggml
     return acc;
 }
 
+/* Q4_1 / Q5_1 against Q8_1 (ggml-cpu-quants.c:2910-2925, 3572-3592): (dx*dy)*sumi + mx*sy per block;
+ * Q5_0 / IQ4_NL against Q8_0 (:3227-3248, 12652-12660) */
+static float dot_legacy(int type, int64_t k, const uint8_t *w, const uint8_t *a) {
+    const size_t ts = qmo_type_size(type);
+    const int q81 = type == QMO_Q4_1 || type == QMO_Q5_1;
+    float acc = 0.0f;
+    for (int64_t b = 0; b < k / 32; ++b, w += ts, a += q81 ? 36 : 34) {
+        const int8_t *y = (const int8_t *)(a + (q81 ? 4 : 2));
+        int s0 = 0, s1 = 0;
+        if (type == QMO_Q4_1) {
+            const uint8_t *qs = w + 4;
+            for (int j = 0; j < 16; ++j) { s0 += (qs[j] & 15) * y[j]; s1 += (qs[j] >> 4) * y[j + 16]; }
+        } else if (type == QMO_IQ4_NL) {
+            const uint8_t *qs = w + 2;
+            for (int j = 0; j < 16; ++j) { s0 += y[j] * iq4nl_values[qs[j] & 15]; s1 += y[j + 16] * iq4nl_values[qs[j] >> 4]; }
+        } else {
+            const int one = type == QMO_Q5_1;
+            uint32_t qh; memcpy(&qh, w + (one ? 4 : 2), 4);
+            const uint8_t *qs = w + (one ? 8 : 6);
+            for (int j = 0; j < 16; ++j) {
+                const int x0 = ((qs[j] & 15) | (int)(((qh >> j) & 1u) << 4)) - (one ? 0 : 16);
+                const int x1 = ((qs[j] >> 4) | (int)(((qh >> (j + 16)) & 1u) << 4)) - (one ? 0 : 16);
+                s0 += x0 * y[j];
+                s1 += x1 * y[j + 16];
+            }
+        }
+        const int sumi = s0 + s1;
+        if (q81)                     acc += (rd_f16(w) * rd_f16(a)) * (float)sumi + rd_f16(w + 2) * rd_f16(a + 2);
+        else if (type == QMO_IQ4_NL) acc += (rd_f16(a) * rd_f16(w)) * (float)sumi;            /* d = dy*dx; d * (sumi1 + sumi2) */
+        else                         acc += (rd_f16(w) * rd_f16(a)) * (float)sumi;
+    }
+    return acc;
+}
+
+static float dot_q2_K(int64_t k, const uint8_t *w, const uint8_t *a) {   /* ggml-cpu-quants.c:5484-5523 */
+    float acc = 0.0f;
+    for (int64_t b = 0; b < k / 256; ++b, w += 84, a += 292) {
+        const uint8_t *sc = w, *qs = w + 16;
+        float yd; memcpy(&yd, a, 4);
+        const int8_t *q8 = (const int8_t *)(a + 4);
+        int16_t bsums[16]; memcpy(bsums, a + 260, 32);
+        int summs = 0;
+        for (int j = 0; j < 16; ++j) summs += bsums[j] * (sc[j] >> 4);
+        const float dall = yd * rd_f16(w + 80), dmin = yd * rd_f16(w + 82);
+        int isum = 0;
+        for (int g = 0; g < 16; ++g) {
+            const uint8_t *q = qs + 32 * (g >> 3) + 16 * (g & 1);
+            const int shift = 2 * ((g & 7) >> 1);
+            int l16 = 0;
+            for (int l = 0; l < 16; ++l) l16 += q8[16 * g + l] * ((q[l] >> shift) & 3);
+            isum += (sc[g] & 15) * l16;
+        }
+        acc += dall * (float)isum - dmin * (float)summs;
+    }
+    return acc;
+}
+
+static float dot_q3_K(int64_t k, const uint8_t *w, const uint8_t *a) {   /* ggml-cpu-quants.c:6600-6661: eight f32 lanes */
+    float lanes[8] = {0};
+    for (int64_t b = 0; b < k / 256; ++b, w += 110, a += 292) {
+        const uint8_t *hm = w, *qs = w + 32, *s12 = w + 96;
+        float yd; memcpy(&yd, a, 4);
+        const int8_t *q8 = (const int8_t *)(a + 4);
+        int32_t part[8] = {0};
+        for (int g = 0; g < 16; ++g) {
+            const uint8_t *q = qs + 32 * (g >> 3) + 16 * (g & 1), *h = hm + 16 * (g & 1);
+            const int shift = 2 * ((g & 7) >> 1), bit = g >> 1, scale = q3k_scale(s12, g);
+            for (int l = 0; l < 16; ++l) {
+                const int v = (int)((q[l] >> shift) & 3) - (((h[l] >> bit) & 1) ? 0 : 4);
+                part[l & 7] += scale * (int16_t)(q8[16 * g + l] * v);
+            }
+        }
+        const float d = rd_f16(w + 108) * yd;
+        for (int l = 0; l < 8; ++l) lanes[l] += d * (float)part[l];
+    }
+    float acc = 0.0f;
+    for (int l = 0; l < 8; ++l) acc += lanes[l];
+    return acc;
+}
+
 float qmo_vec_dot(int type, int64_t k, const void *w_row, const void *act_row) {
     const uint8_t *w = (const uint8_t *)w_row, *a = (const uint8_t *)act_row;
     switch (type) {
@@ -350,6 +517,9 @@ float qmo_vec_dot(int type, int64_t k, const void *w_row, const void *act_row) {
         case QMO_Q8_0: return dot_q8_0(k, w, a);
         case QMO_Q4_K: case QMO_Q5_K: return dot_q45_K(type, k, w, a);
         case QMO_Q6_K: return dot_q6_K(k, w, a);
+        case QMO_Q4_1: case QMO_Q5_0: case QMO_Q5_1: case QMO_IQ4_NL: return dot_legacy(type, k, w, a);
+        case QMO_Q2_K: return dot_q2_K(k, w, a);
+        case QMO_Q3_K: return dot_q3_K(k, w, a);
         default: return NAN;
     }
 }
@@ -364,8 +534,9 @@ static void *quantize_acts(int type, const float *x, int64_t K, int64_t rows, in
     if (!buf) return NULL;
     #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < rows; ++n) {              /* phase 1, ggml-cpu.c:6807-6842 */
-        if (vt == QMO_Q8_0) qmo_quantize_row_q8_0(x + n * ldx, buf + n * *row_bytes, K, act_mode);
-        else                qmo_quantize_row_q8_K(x + n * ldx, buf + n * *row_bytes, K);
+        if (vt == QMO_Q8_0)      qmo_quantize_row_q8_0(x + n * ldx, buf + n * *row_bytes, K, act_mode);
+        else if (vt == QMO_Q8_1) qmo_quantize_row_q8_1(x + n * ldx, buf + n * *row_bytes, K, act_mode);
+        else                     qmo_quantize_row_q8_K(x + n * ldx, buf + n * *row_bytes, K);
     }
     return buf;
 }

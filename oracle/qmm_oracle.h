@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-enum { QMO_Q4_0 = 2, QMO_Q8_0 = 8, QMO_Q4_K = 12, QMO_Q5_K = 13, QMO_Q6_K = 14, QMO_Q8_K = 15 };
+enum { QMO_Q4_0 = 2, QMO_Q4_1 = 3, QMO_Q5_0 = 6, QMO_Q5_1 = 7, QMO_Q8_0 = 8, QMO_Q8_1 = 9, QMO_Q2_K = 10, QMO_Q3_K = 11,
+       QMO_Q4_K = 12, QMO_Q5_K = 13, QMO_Q6_K = 14, QMO_Q8_K = 15, QMO_IQ4_NL = 20 };
 
 /* activation rounding variant (all three exist in the reference; bytes differ only on rare ties) */
 enum { QMO_ACT_REF = 0,   /* quantize_row_q8_0_ref: id = 1/(amax/127), roundf          ggml-quants.c:194-217      */
@@ -34,19 +35,21 @@ enum { QMO_ACT_REF = 0,   /* quantize_row_q8_0_ref: id = 1/(amax/127), roundf   
 int    qmo_blck_size(int type);                 /* 32 or 256; 0 if unsupported */
 size_t qmo_type_size(int type);                 /* bytes per block            */
 size_t qmo_row_size(int type, int64_t k);       /* k/blck*type_size           */
-int    qmo_vec_dot_type(int type);              /* Q8_0 for Q4_0/Q8_0, Q8_K for K-quants (ggml-cpu.c:256-…) */
+int    qmo_vec_dot_type(int type);              /* Q8_0 for Q4_0/Q5_0/Q8_0/IQ4_NL, Q8_1 for Q4_1/Q5_1, Q8_K for K-quants (ggml-cpu.c:256-…) */
 
 float    qmo_fp16_to_fp32(uint16_t h);
 uint16_t qmo_fp32_to_fp16(float f);
 
-/* block unpack, bit-exact spec (ggml-quants.c:255-273, 349-363, 1280-1302, 1482-1508, 1690-1722) */
+/* block unpack, bit-exact spec (ggml-quants.c:255-273, 275-347, 349-363, 712-745, 1056-1106, 1280-1302, 1482-1508, 1690-1722, 2436-2453) */
 int qmo_dequantize_row(int type, const void *src, float *dst, int64_t k);
 
 /* activation quantizers (ggml-quants.c:194-217, 2479-2516) */
 void qmo_quantize_row_q8_0(const float *x, void *y, int64_t k, int act_mode);
+void qmo_quantize_row_q8_1(const float *x, void *y, int64_t k, int act_mode);   /* ggml-quants.c:220-252; AVX2: ggml-cpu-quants.c:1053-… */
 void qmo_quantize_row_q8_K(const float *x, void *y, int64_t k);
 
-/* one row dot, scalar summation order (ggml-cpu-quants.c:2591-2607, 4004-4015, 7535-7591, 8351-8412, 9423-9465) */
+/* one row dot, scalar summation order (ggml-cpu-quants.c:2591-2607, 2910-2925, 3227-3248, 3572-3592, 4004-4015, 5484-5523,
+ * 6600-6661, 7535-7591, 8351-8412, 9423-9465, 12652-12660) */
 float qmo_vec_dot(int type, int64_t k, const void *w_row, const void *act_row);
 
 /* dst[n*ldd + m] = W[m,:] . x[n,:]   (ggml-cpu.c:6745-6937 with nth=1, no llamafile path)

@@ -33,13 +33,20 @@ struct Config {
     const char * name;
     int n_layer, n_embd, n_ff, n_head, n_head_kv, n_vocab;
     float rope_base;
-    const char * recipe;     // q4_0 | q4_k | q4_k_m
+    const char * recipe;     // q4_0 | q4_k | q4_k_m | q5_0 | q3_k_m | mix
     int n_expert, n_used;
 };
 static const Config CONFIGS[] = {
     { "tiny-q4_k_m",        4, 1024,  2816,  8, 2,   4096,  10000.0f, "q4_k_m", 0, 0 },
     { "tiny-q4_0",          2, 1024,  2816,  8, 8,   4096,  10000.0f, "q4_0",   0, 0 },
     { "tiny-moe-q4_k_m",    2, 1024,  2816,  8, 2,   4096,  10000.0f, "q4_k_m", 8, 2 },
+    // SURVEY 8f-4 formats: a stock "Q5_0" file (Q5_0 everywhere, Q6_K output), llama-quant.cpp's Q3_K_M (src/llama-quant.cpp:228-229,
+    // 279-283, 326: Q3_K with attn_v Q5_K / Q4_K, attn_output Q4_K, ffn_down Q5_K / Q4_K), and one layer set that carries every
+    // remaining format (Q4_1, Q5_1, IQ4_NL, Q5_0, Q2_K, Q3_K)
+    { "tiny-q5_0",          2, 1024,  2816,  8, 8,   4096,  10000.0f, "q5_0",   0, 0 },
+    { "tiny-q3_k_m",        4, 1024,  2816,  8, 2,   4096,  10000.0f, "q3_k_m", 0, 0 },
+    { "tiny-mix",           2, 1024,  2816,  8, 2,   4096,  10000.0f, "mix",    0, 0 },
+    { "llama3-8b-q3_k_m",  32, 4096, 14336, 32, 8,  128256, 500000.0f, "q3_k_m", 0, 0 },
     { "llama2-7b-q4_0",    32, 4096, 11008, 32, 32,  32000, 10000.0f, "q4_0",   0, 0 },
     { "llama3-8b-q4_k_m",  32, 4096, 14336, 32, 8,  128256, 500000.0f, "q4_k_m", 0, 0 },
     { "synth-7b-q4_k",     32, 4096, 11008, 32, 32,  32000, 10000.0f, "q4_k",   0, 0 },
@@ -59,15 +66,22 @@ struct TensorSpec {
 // per-tensor types of llama-quant.cpp's recipes (same table as ggml-hexagon_amd/workload.py)
 static std::vector<TensorSpec> tensor_list(const Config & c) {
     std::vector<TensorSpec> ts;
-    const bool q40 = !strcmp(c.recipe, "q4_0"), q4k = !strcmp(c.recipe, "q4_k");
-    const ggml_type base = q40 ? GGML_TYPE_Q4_0 : GGML_TYPE_Q4_K;
+    const bool q40 = !strcmp(c.recipe, "q4_0"), q4k = !strcmp(c.recipe, "q4_k"), q50 = !strcmp(c.recipe, "q5_0"), q3km = !strcmp(c.recipe, "q3_k_m"),
+               mix = !strcmp(c.recipe, "mix");
+    const ggml_type base = q40 ? GGML_TYPE_Q4_0 : q50 ? GGML_TYPE_Q5_0 : q3km ? GGML_TYPE_Q3_K : mix ? GGML_TYPE_Q4_1 : GGML_TYPE_Q4_K;
     const int64_t kv = (int64_t) c.n_embd / c.n_head * c.n_head_kv;
     ts.push_back({ "token_embd.weight", base, { c.n_embd, c.n_vocab, 1 }, 2 });
     ts.push_back({ "output_norm.weight", GGML_TYPE_F32, { c.n_embd, 1, 1 }, 1 });
     ts.push_back({ "output.weight", q4k ? GGML_TYPE_Q4_K : GGML_TYPE_Q6_K, { c.n_embd, c.n_vocab, 1 }, 2 });
     for (int i = 0; i < c.n_layer; ++i) {
         ggml_type tq = base, tk = base, tv = base, to = base, tg = base, td = base;
-        if (!q40 && !q4k) {
+        if (q3km) {
+            tv = i < 2 ? GGML_TYPE_Q5_K : GGML_TYPE_Q4_K;
+            to = GGML_TYPE_Q4_K;
+            td = i < c.n_layer / 16 ? GGML_TYPE_Q5_K : GGML_TYPE_Q4_K;
+        } else if (mix) {
+            tq = GGML_TYPE_Q4_1; tk = GGML_TYPE_Q5_1; tv = GGML_TYPE_IQ4_NL; to = GGML_TYPE_Q5_0; tg = GGML_TYPE_Q2_K; td = GGML_TYPE_Q3_K;
+        } else if (!q40 && !q4k && !q50) {
             const bool more = use_more_bits(i, c.n_layer);
             tv = td = more ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K;
             if (c.n_layer >= 80 && tv == GGML_TYPE_Q4_K) tv = GGML_TYPE_Q5_K;
@@ -173,8 +187,20 @@ static int write_gguf(const Config & c, const char * path) {
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// where the loader put the weights: llama.cpp logs one "<buffer type> model buffer size = N MiB" line per buffer type
+// (src/llama-model.cpp load_tensors); kept for the JSON so that a test can see that only the input embedding (always a CPU
+// tensor, src/llama-model.cpp:1435) stayed on the host
+static std::string g_buffers;
 static void quiet_log(ggml_log_level level, const char * text, void *) {
     if (level >= GGML_LOG_LEVEL_WARN) fputs(text, stderr);
+    const char * p = strstr(text, "model buffer size =");
+    if (p) {
+        const char * b = text;
+        while (*b == ' ' || !strncmp(b, "load_tensors:", 13)) b += (*b == ' ') ? 1 : 13;
+        std::string name(b, p);
+        while (!name.empty() && name.back() == ' ') name.pop_back();
+        g_buffers += (g_buffers.empty() ? "\"" : ", \"") + name + "\": " + std::to_string(atof(p + 19));
+    }
 }
 
 struct Session {
@@ -286,7 +312,8 @@ int main(int argc, char ** argv) {
         for (double v : pps) pp_s += v / pps.size();
         for (double v : tgs) tg_s += v / tgs.size();
         printf("{\"mode\": \"bench\", \"gguf\": \"%s\", \"ngl\": %d, \"devices\": \"%s\", \"threads\": %d, \"n_prompt\": %d, \"n_gen\": %d, \"reps\": %d, "
-               "\"pp_tok_s\": %.2f, \"tg_tok_s\": %.2f}\n", gguf, ngl, devs.c_str(), threads, n_prompt, n_gen, reps, pp_s, tg_s);
+               "\"pp_tok_s\": %.2f, \"tg_tok_s\": %.2f, \"model_buffers_MiB\": {%s}}\n", gguf, ngl, devs.c_str(), threads, n_prompt, n_gen, reps, pp_s, tg_s,
+               g_buffers.c_str());
         s.close();
         return 0;
     }

@@ -21,7 +21,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
-from oracle.pyoracle import Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, TYPE_NAMES, RefGgml  # noqa: E402
+from oracle.pyoracle import Q2_K, Q3_K, Q4_0, Q4_1, Q4_K, Q5_0, Q5_1, Q5_K, Q6_K, Q8_0, IQ4_NL, TYPE_NAMES, WEIGHT_TYPES, RefGgml  # noqa: E402
 import ggml_hexagon_amd.synth as synth  # noqa: E402
 
 K, M = 512, 40
@@ -33,24 +33,25 @@ def edge_blocks(t, rng):
     ts, bs = synth.TYPE_SIZE[t], synth.BLCK[t]
     nb = K // bs
     blk = rng.integers(0, 256, (nb, ts), dtype=np.uint8)
-    doff = 208 if t == Q6_K else 0
+    doff = {Q6_K: 208, Q2_K: 80, Q3_K: 108}.get(t, 0)
+    two = {Q4_K: 2, Q5_K: 2, Q4_1: 2, Q5_1: 2, Q2_K: 82}          # offset of the second fp16 (dmin / m), where there is one
 
     def set_d(i, h, off=doff):
         blk[i, off:off + 2] = np.array([h], np.uint16).view(np.uint8)
 
     for i in range(nb):
         set_d(i, 0x2A00 + 37 * i)                  # ~0.047: sane
-        if t in (Q4_K, Q5_K):
-            set_d(i, 0x2C00 + 11 * i, 2)
+        if t in two:
+            set_d(i, 0x2C00 + 11 * i, two[t])
     blk[0, :] = 0                                   # all-zero block
     blk[1 % nb, :] = 0xFF                           # every field at max (d = NaN pattern replaced below)
     set_d(1 % nb, 0xABCD)                           # negative d
-    if t in (Q4_K, Q5_K):
-        set_d(1 % nb, 0x3555, 2)
+    if t in two:
+        set_d(1 % nb, 0x3555, two[t])
     if nb > 2:
         set_d(2, 0x0001)                            # smallest fp16 subnormal
-        if t in (Q4_K, Q5_K):
-            set_d(2, 0x03FF, 2)                     # largest subnormal dmin
+        if t in two:
+            set_d(2, 0x03FF, two[t])                # largest subnormal dmin / m
     if nb > 3:
         set_d(3, 0x0000)                            # d == 0
     if nb > 4:
@@ -73,7 +74,10 @@ def act_rows(rng):
 
 def main():
     r = RefGgml("avx2")
-    for t in (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K):
+    only = [a for a in sys.argv[1:]]
+    for t in WEIGHT_TYPES:
+        if only and TYPE_NAMES[t] not in only:
+            continue
         rng = np.random.default_rng(1000 + t)
         w = np.concatenate([
             r.quantize_weights(t, rng.uniform(-1, 1, (M - 9, K)).astype(np.float32)),

@@ -31,7 +31,7 @@ def run(*args, env=None, timeout=600):
     return json.loads(lines[-1]) if lines else None
 
 
-@pytest.fixture(scope="module", params=["tiny-q4_k_m", "tiny-q4_0"])
+@pytest.fixture(scope="module", params=["tiny-q4_k_m", "tiny-q4_0", "tiny-q5_0", "tiny-q3_k_m", "tiny-mix"])
 def gguf(request, tmp_path_factory):
     path = tmp_path_factory.mktemp("gguf") / f"{request.param}.gguf"
     run("write", "--config", request.param, "--gguf", str(path))
@@ -57,6 +57,12 @@ def test_llama_bench_protocol_runs(gguf):
     r = run("bench", "--gguf", gguf, "-p", "128", "-n", "16", "-r", "1", "-t", "8")
     print(r)
     assert r["pp_tok_s"] > 0 and r["tg_tok_s"] > 0
+    # every matmul weight of the file is in the device's buffer: what stays in a CPU buffer is the input embedding alone
+    # (token_embd [1024, 4096] in the file's base type, at most 4.5 MiB as Q8_0), whatever quant formats the recipe mixes
+    buf = r["model_buffers_MiB"]
+    dev_mib = sum(v for k, v in buf.items() if "MI355X" in k)
+    cpu_mib = sum(v for k, v in buf.items() if "MI355X" not in k)
+    assert dev_mib > 10 and cpu_mib < 5, buf
 
 
 @pytest.mark.parametrize("sm,vd", [("layer", "2"), ("row", "2"), ("row", "3")])

@@ -15,10 +15,11 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-from oracle.pyoracle import ACT_REF, ACT_X86, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, Q8_K, TYPE_NAMES  # noqa: E402
+from oracle.pyoracle import ACT_REF, ACT_X86, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, Q8_K, TYPE_NAMES, WEIGHT_TYPES, vec_dot_type  # noqa: E402
 
-ALL = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K)
+ALL = WEIGHT_TYPES          # the north-star's five + SURVEY 8f-4's six (Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL)
 IDS = [TYPE_NAMES[t] for t in ALL]
+LEGACY = tuple(t for t in ALL if vec_dot_type(t) != Q8_K)      # 32-weight blocks
 
 
 @pytest.fixture(scope="module")
@@ -77,7 +78,7 @@ def test_dequant_golden_bit_exact(qmm, golden):
 @pytest.mark.parametrize("t", ALL, ids=IDS)
 def test_dequant_random_blocks_bit_exact(qmm, oracle, t):
     import ggml_hexagon_amd.synth as synth
-    k = 2048 if t in (Q4_0, Q8_0) else 4096
+    k = 2048 if t in LEGACY else 4096
     w = synth.synth_weights(t, 37, k, seed=11)
     got = qmm.dequantize(t, dev(w), k).cpu().numpy()
     want = oracle.dequantize(t, w, k)
@@ -87,7 +88,7 @@ def test_dequant_random_blocks_bit_exact(qmm, oracle, t):
 @pytest.mark.parametrize("mode", [ACT_REF, ACT_X86])
 def test_activation_quantizer_bit_exact(qmm, oracle, golden, mode):
     t = int(golden["type"])
-    vt = Q8_0 if t in (Q4_0, Q8_0) else Q8_K
+    vt = vec_dot_type(t)
     rng = np.random.default_rng(3)
     x = np.concatenate([golden["act"], rng.standard_normal((21, 512)).astype(np.float32) * 5])
     qmm.set_act_mode(mode)
@@ -99,6 +100,12 @@ def test_activation_quantizer_bit_exact(qmm, oracle, golden, mode):
         blk = wire.reshape(rows, -1, 34)
         want_d = blk[:, :, :2].copy().view(np.float16).astype(np.float32).reshape(rows, -1)
         want_q = blk[:, :, 2:].copy().view(np.int8).reshape(rows, -1)
+    elif vt == 9:                                                # Q8_1: d, s = f16(d * sum), 32 int8 (ggml-common.h:216-227)
+        blk = wire.reshape(rows, -1, 36)
+        want_d = blk[:, :, :2].copy().view(np.float16).astype(np.float32).reshape(rows, -1)
+        want_s = blk[:, :, 2:4].copy().view(np.float16).astype(np.float32).reshape(rows, -1)
+        want_q = blk[:, :, 4:].copy().view(np.int8).reshape(rows, -1)
+        assert np.array_equal(bs.cpu().numpy().view(np.uint32), want_s.view(np.uint32))
     else:
         blk = wire.reshape(rows, -1, 292)
         want_d = blk[:, :, :4].copy().view(np.float32).reshape(rows, -1)
@@ -150,12 +157,12 @@ def test_matvec_vs_oracle(qmm, oracle, maybe_ref, t, n):
 def test_matvec_small_and_ragged_shapes(qmm, oracle, t):
     """test-backend-ops shapes: m=16,k=256 (tests/test-backend-ops.cpp:4132-4136); k = one block; m = 1"""
     import ggml_hexagon_amd.synth as synth
-    for (m, k, n) in ((16, 256, 1), (16, 256, 8), (1, 256, 3), (5, 512 if t in (Q4_0, Q8_0) else 768, 2)):
+    for (m, k, n) in ((16, 256, 1), (16, 256, 8), (1, 256, 3), (5, 512 if t in LEGACY else 768, 2)):
         w = synth.synth_weights(t, m, k, seed=m + k, sigma=0.2)
         x = np.random.default_rng(k).uniform(-1, 1, (n, k)).astype(np.float32)
         got = qmm.mul_mat(t, dev(w), k, dev(x)).cpu().numpy()
         assert rel_rms(got, oracle.mul_mat(t, w, k, x, ACT_REF)) < 2e-5
-    if t in (Q4_0, Q8_0):                                       # k = blck (32)
+    if t in LEGACY:                                             # k = blck (32)
         w = synth.synth_weights(t, 7, 32, seed=1, sigma=0.2)
         x = np.random.default_rng(0).uniform(-1, 1, (2, 32)).astype(np.float32)
         got = qmm.mul_mat(t, dev(w), 32, dev(x)).cpu().numpy()
@@ -209,7 +216,7 @@ def test_prefill_group_one_tiled_launch(qmm, oracle, t):
     """same-type matrices sharing src1 at prefill batch sizes go out as ONE tiled launch (+ one split-K reduce): every
     matrix against the oracle and identical to its own single launch; ragged row counts, strided dst, 2 to 4 matrices"""
     import ggml_hexagon_amd.synth as synth
-    kblk = 32 if t in (Q4_0, Q8_0) else 256
+    kblk = 32 if t in LEGACY else 256
     for k, ms, n in ((kblk * (2048 // kblk), (512, 128, 128), 300), (kblk * (1024 // kblk), (300, 70), 200), (kblk * (1536 // kblk), (256, 256, 1, 33), 512)):
         ws_np = [synth.synth_weights(t, m, k, seed=m + i, sigma=0.25) for i, m in enumerate(ms)]
         ws = [(t, dev(w)) for w in ws_np]
@@ -411,7 +418,7 @@ def test_random_shapes_sweep_every_kernel(qmm, oracle, t):
     dispatch boundary (mat-vec <= 8 < few-token kernel <= 64/128 < tiled kernel, with and without split-K)"""
     import ggml_hexagon_amd.synth as synth
     rng = np.random.default_rng(1000 + t)
-    kblk = 32 if t in (Q4_0, Q8_0) else 256
+    kblk = 32 if t in LEGACY else 256
     n_choices = [1, 2, 7, 8, 9, 17, 31, 32, 33, 63, 64, 65, 100, 128, 129, 200, 257, 300]
     for case in range(14):
         m = int(rng.integers(1, 700))
@@ -443,7 +450,7 @@ def test_bad_arguments_fail_loudly(qmm):
 
     assert call() == 0
     assert call(n=0) == 0                                     # empty batch: nothing to do
-    for kwargs, needle in ((dict(t=10), "type"), (dict(t=0), "type"), (dict(kk=k - 32), "multiple"), (dict(rb=w.stride(0) - 2), "stride"),
+    for kwargs, needle in ((dict(t=16), "type"), (dict(t=0), "type"), (dict(kk=k - 32), "multiple"), (dict(rb=w.stride(0) - 2), "stride"),
                            (dict(xp=x.data_ptr() + 4), "aligned"), (dict(ldx=k - 4), "ldx"), (dict(ldd=m - 1), "ldd")):
         rc = call(**kwargs)
         assert rc < 0, kwargs

@@ -24,10 +24,11 @@ def test_capi_exports_every_declared_symbol():
         for name in declared:
             assert hasattr(lib, name), f"{name} declared in include/{hdr} but not exported"
         assert set(declared) == set(exports)
-    assert lib.qmm_abi_version() == 1
+    assert lib.qmm_abi_version() == 2            # 2: chains, timing events, six more weight formats, Q8_1 activations
     lib.qmm_row_size.restype = ctypes.c_size_t
     lib.qmm_row_size.argtypes = [ctypes.c_int, ctypes.c_int64]
     assert [lib.qmm_row_size(t, 4096) for t in (2, 8, 12, 13, 14)] == [2304, 4352, 2304, 2816, 3360]
+    assert [lib.qmm_row_size(t, 4096) for t in (3, 6, 7, 10, 11, 20)] == [2560, 2816, 3072, 1344, 1760, 2304]     # SURVEY 8f-4 formats
     assert lib.qmm_row_size(12, 100) == 0 and lib.qmm_row_size(0, 4096) == 0
 
 

@@ -3,9 +3,9 @@
 import numpy as np
 import pytest
 
-from oracle.pyoracle import ACT_REF, ACT_X86, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, TYPE_NAMES
+from oracle.pyoracle import ACT_REF, ACT_X86, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, Q8_K, TYPE_NAMES, WEIGHT_TYPES, vec_dot_type
 
-ALL = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K)
+ALL = WEIGHT_TYPES
 
 
 def rel_rms(a, b):
@@ -14,8 +14,9 @@ def rel_rms(a, b):
 
 def test_type_table(oracle):
     # ggml-common.h block sizes; bytes/weight of SURVEY.md §8d
-    assert [oracle.lib.qmo_type_size(t) for t in ALL] == [18, 34, 144, 176, 210]
-    assert [oracle.lib.qmo_blck_size(t) for t in ALL] == [32, 32, 256, 256, 256]
+    assert [oracle.lib.qmo_type_size(t) for t in ALL] == [18, 34, 144, 176, 210, 20, 22, 24, 84, 110, 18]
+    assert [oracle.lib.qmo_blck_size(t) for t in ALL] == [32, 32, 256, 256, 256, 32, 32, 32, 256, 256, 32]
+    assert oracle.lib.qmo_type_size(9) == 36                        # Q8_1: d, s, 32 int8
     assert oracle.row_size(Q4_K, 4096) == 4096 // 256 * 144
     assert oracle.lib.qmo_type_size(15) == 292
 
@@ -44,7 +45,7 @@ def test_activation_bytes(oracle, golden):
     x = golden["act"]
     assert np.array_equal(oracle.quantize_act(t, x, ACT_REF), golden["act_q_ref"])
     got = oracle.quantize_act(t, x, ACT_X86)
-    if t in (Q4_0, Q8_0):
+    if vec_dot_type(t) != Q8_K:                      # Q8_0 / Q8_1: the scalar and the AVX2 quantizer
         assert np.array_equal(got, golden["act_q_cpu"])
     else:  # Q8_K has one implementation on x86 (the _ref one)
         assert np.array_equal(golden["act_q_cpu"], golden["act_q_ref"])
