@@ -18,7 +18,7 @@ EXPORTS = [
     "qmm_device_info", "qmm_set_act_mode", "qmm_set_precision", "qmm_malloc", "qmm_free", "qmm_host_malloc", "qmm_host_free", "qmm_memcpy_h2d",
     "qmm_memcpy_d2h", "qmm_memcpy_d2d", "qmm_memset", "qmm_synchronize", "qmm_memcpy2d_d2d", "qmm_event_create",
     "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_event_create_timing", "qmm_event_elapsed_ms", "qmm_memcpy_h2d_async",
-    "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_dequantize",
+    "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_planar_type", "qmm_repack_rows", "qmm_dequantize",
     "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_swiglu_in", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
     "qmm_chain_begin", "qmm_chain_flush", "qmm_chain_end", "qmm_chain_stats", "qmm_chain_debug",
 ]
@@ -103,6 +103,8 @@ def load_library() -> C.CDLL:
     lib.qmm_row_size.restype = sz
     lib.qmm_row_size.argtypes = [i32, i64]
     lib.qmm_dequantize.argtypes = [v, i32, v, i64, i64, i64, v, v]
+    lib.qmm_planar_type.argtypes = [i32, i64, i64]
+    lib.qmm_repack_rows.argtypes = [v, i32, v, i64, i64, i64, i32, v]
     lib.qmm_quantize_act.argtypes = [v, i32, v, i64, i64, i64, v, v, v, v]
     lib.qmm_mul_mat.argtypes = [v, i32, v, i64, i64, i64, v, i64, i64, v, i64, v]
     lib.qmm_mul_mat_group.argtypes = [v, C.POINTER(QmmWeight), i32, i64, v, i64, i64, v]
@@ -187,6 +189,16 @@ class Qmm:
         a, b = C.c_int(0), C.c_int(0)
         self._chk(self.lib.qmm_chain_stats(self.ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def planar_type(self, t, k, row_bytes):
+        return self.lib.qmm_planar_type(t, k, row_bytes)
+
+    def repack_rows(self, t, w, k, to_planar=True):
+        """in place: w uint8 [..., rows, row_bytes] (contiguous rows) between GGUF wire layout and the planar layout; returns the
+        type code to use for w afterwards"""
+        rows = w.numel() // w.shape[-1]
+        self._chk(self.lib.qmm_repack_rows(self.ctx, t, w.data_ptr(), w.stride(-2), rows, k, 1 if to_planar else 0, self._stream()))
+        return t + 100 if to_planar else t
 
     # --- torch-tensor conveniences (uint8 weight tensors [M, row_bytes] on the GPU) ---------------
     def dequantize(self, t, w, k):

@@ -108,6 +108,8 @@ static int check_mm(int type, const void * w, int64_t rb, int64_t K, const float
     if (K <= 0 || K % blck(type)) return fail(QMM_EUNSUPPORTED, "%s: K=%lld must be a multiple of %d", who, (long long) K, blck(type));
     if (rb < (int64_t) qmm_row_size(type, K)) return fail(QMM_EINVAL, "%s: weight row stride %lld < row size", who, (long long) rb);
     if ((uintptr_t) x % 16 || ldx % 4 || ldx < K) return fail(QMM_EINVAL, "%s: src1 must be 16-byte aligned with ldx %% 4 == 0", who);
+    if (type_planar(type) && (!qmm_planar_type(type_base(type), K, rb) || (uintptr_t) w % 16))
+        return fail(QMM_EINVAL, "%s: planar type %d wants 16-byte aligned rows and K a multiple of %d", who, type, type_base(type) == T_Q6_K ? 2048 : 256);
     return QMM_OK;
 }
 
@@ -518,6 +520,37 @@ int qmm_dequantize(qmm_ctx * c, int type, const void * w, int64_t rb, int64_t ro
 #undef QMM_X
 }
 
+// ------------------------------------------------------------------------------------------- planar rows
+
+int qmm_planar_type(int type, int64_t K, int64_t w_row_bytes) {
+    if (type != T_Q4_0 && type != T_Q8_0 && type != T_Q6_K) return 0;
+    if (K <= 0 || K % (type == T_Q6_K ? 2048 : 256) || w_row_bytes % 16) return 0;     // planes and rows start on 16-byte boundaries
+    return type + 100;
+}
+
+int qmm_repack_rows(qmm_ctx * c, int type, void * w, int64_t w_row_bytes, int64_t rows, int64_t K, int to_planar, void * st) {
+    if (!c) return fail(QMM_EINVAL, "qmm_repack_rows: NULL context");
+    if (!qmm_planar_type(type, K, w_row_bytes) || (uintptr_t) w % 16 || w_row_bytes < (int64_t) qmm_row_size(type, K))
+        return fail(QMM_EUNSUPPORTED, "qmm_repack_rows: type %d, K=%lld, row stride %lld has no planar form", type, (long long) K, (long long) w_row_bytes);
+    if (rows <= 0) return QMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
+    const size_t lds = qmm_row_size(type, K);
+    if (lds > 150 * 1024) return fail(QMM_EUNSUPPORTED, "qmm_repack_rows: a row of %zu bytes does not fit LDS", lds);
+#define QMM_RP(TT, DIR)                                                                                                             \
+    do {                                                                                                                            \
+        auto kern = repack_rows_kernel<TT, DIR>;                                                                                    \
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); \
+        hipLaunchKernelGGL(kern, dim3((unsigned) rows), dim3(256), lds, c->s(st), (uint8_t *) w, w_row_bytes, (int) K);              \
+    } while (0)
+    if (type == T_Q4_0)      { if (to_planar) QMM_RP(T_Q4_0, true); else QMM_RP(T_Q4_0, false); }
+    else if (type == T_Q8_0) { if (to_planar) QMM_RP(T_Q8_0, true); else QMM_RP(T_Q8_0, false); }
+    else                     { if (to_planar) QMM_RP(T_Q6_K, true); else QMM_RP(T_Q6_K, false); }
+#undef QMM_RP
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
 // ------------------------------------------------------------------------------------------- quantize_act
 
 int qmm_quantize_act(qmm_ctx * c, int vt, const float * x, int64_t rows, int64_t K, int64_t ldx,
@@ -584,7 +617,7 @@ static int mul_mat_group_impl(qmm_ctx * c, const qmm_weight * ws, int nw, int64_
         // K-quant matrices of different types share the Q8_K activations: one mixed-type launch for the whole group
         bool kq = true, mixed = false;
         for (int i = 0; i < nw; ++i) {
-            kq = kq && (ws[i].type == T_Q4_K || ws[i].type == T_Q5_K || ws[i].type == T_Q6_K) && ws[i].M > 0;
+            kq = kq && (ws[i].type == T_Q4_K || ws[i].type == T_Q5_K || ws[i].type == T_Q6_K || ws[i].type == T_Q6_KP) && ws[i].M > 0;
             mixed = mixed || ws[i].type != ws[0].type;
         }
         if (kq && mixed && (size_t) N * K * 11 / 8 + 4096 <= 150 * 1024) {

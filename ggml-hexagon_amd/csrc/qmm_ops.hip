@@ -511,7 +511,7 @@ get_rows_q_kernel(const uint8_t * __restrict__ x, const char * __restrict__ ids,
     const int units = (int) (sx.ne[0] / Traits<T>::UNIT_W);
     for (int u = threadIdx.x; u < units; u += 256) {
         Unit<T> un;
-        un.load(px, u);
+        un.load(px, u, (int) sx.ne[0]);
         float out[Traits<T>::UNIT_W];
         un.to_f32(u, out);
 #pragma unroll

@@ -119,6 +119,17 @@ QMM_API int          qmm_event_synchronize(qmm_ctx * ctx, qmm_event * ev);      
 
 QMM_API size_t       qmm_row_size(int type, int64_t k);
 
+/* Planar rows (weight repack at set_tensor; precedent ggml_backend_amx_buffer_set_tensor, ggml/src/ggml-cpu/amx/amx.cpp,
+ * which converts to its own layout on upload).  Q4_0, Q8_0 and Q6_K blocks are 18, 34 and 210 bytes, so a lane's 16-byte loads sit at
+ * 2-byte alignment in GGUF wire layout.  The planar form keeps every row's bytes in the row and re-lays them as aligned planes:
+ *   Q4_0P [d: nb x 2][qs: nb x 16]   Q8_0P [d: nb x 2][qs: nb x 32]   Q6_KP [ql: nb x 128][qh: nb x 64][scales: nb x 16][d: nb x 2]
+ * Row size and stride do not change.  qmm_planar_type returns the type code to pass to every entry point of this header for rows
+ * in that form (type + 100), or 0 when (type, K, row stride) has none (K % 256, for Q6_K K % 2048, stride % 16).
+ * qmm_repack_rows converts `rows` rows IN PLACE, to_planar != 0: wire -> planar, 0: back (byte-exact inverse).  `type` is the
+ * wire type; w must be 16-byte aligned. */
+QMM_API int qmm_planar_type(int type, int64_t K, int64_t w_row_bytes);
+QMM_API int qmm_repack_rows(qmm_ctx * ctx, int type, void * w, int64_t w_row_bytes, int64_t rows, int64_t K, int to_planar, void * stream);
+
 /* dst f32 [rows, K] (contiguous) = bit-exact unpack of `rows` weight rows */
 QMM_API int qmm_dequantize(qmm_ctx * ctx, int type, const void * w, int64_t w_row_bytes,
                            int64_t rows, int64_t K, float * dst, void * stream);
