@@ -49,12 +49,12 @@ def roofline_leg(hp, q, n_batch, torch, n_outputs=None):
             outs = [dst_local[("id", m.name.split(".")[-1], m.M)] for m in grp.mats]
             if len(grp.mats) == 2 and grp.mats[1].type == m0.type:
                 fn = (lambda m0=m0, ws=ws, outs=outs, ne11=ne11, x=x, ids=ids:
-                      q.mul_mat_id_pair(m0.type, ws[0], ws[1], m0.K, x[(m0.K, ne11)], ids[:, :m0.n_used], outs[0], outs[1]))
+                      q.mul_mat_id_pair(hp.types[m0.name], ws[0], ws[1], m0.K, x[(m0.K, ne11)], ids[:, :m0.n_used], outs[0], outs[1]))
                 buckets.setdefault(("id", m0.type, n_tokens > 8), []).append(
                     (fn, sum(m.algo_bytes(n_tokens) for m in grp.mats) - n_tokens * m0.K * 4, sum(m.flops(n_tokens) for m in grp.mats)))
             else:
                 for m, w, o in zip(grp.mats, ws, outs):
-                    fn = (lambda m=m, w=w, o=o, ne11=ne11, x=x, ids=ids: q.mul_mat_id(m.type, w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=o))
+                    fn = (lambda m=m, w=w, o=o, ne11=ne11, x=x, ids=ids: q.mul_mat_id(hp.types[m.name], w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=o))
                     buckets.setdefault(("id", m.type, n_tokens > 8), []).append((fn, m.algo_bytes(n_tokens), m.flops(n_tokens)))
             continue
         # one launch per run of same-type weights inside the group (that is how qmm_mul_mat_group issues them)
@@ -68,7 +68,7 @@ def roofline_leg(hp, q, n_batch, torch, n_outputs=None):
             ws, outs, nbytes, fl = [], [], n_tokens * m0.K * 4, 0
             for m in grp.mats[i:j]:
                 w, _ = hp.weights[m.name]
-                ws.append((m.type, w))
+                ws.append((hp.types[m.name], w))
                 outs.append(dst_local[(m.name.split(".")[-1], w.shape[0])])
                 nbytes += w.numel() + n_tokens * w.shape[0] * 4
                 fl += 2 * w.shape[0] * m.K * n_tokens
@@ -243,6 +243,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (llama-bench protocol through libllama: device and CPU)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--wire-layout", action="store_true", help="keep Q4_0 / Q8_0 / Q6_K weights in GGUF wire layout (no planar repack, SURVEY 8f-2)")
     ap.add_argument("--chain", action="store_true", help="token generation as persistent chains (csrc/qmm_chain.hiph) instead of one launch per MUL_MAT group")
     ap.add_argument("--all-logits", action="store_true",
                     help="prompt pass with logits for every token (n_outputs = n_prompt) instead of llama-bench's last-token-only")
@@ -282,7 +283,7 @@ def main():
     q = Qmm(local)
     wl = workload.get(args.workload)
     concat = RowConcat() if world > 1 else None
-    hp = HotPath(q, wl, dev, rank, world, concat)
+    hp = HotPath(q, wl, dev, rank, world, concat, planar=not args.wire_layout)
     hp.chain = args.chain
     hp.prepare(args.n_prompt)
     hp.prepare(1)
@@ -375,7 +376,8 @@ def main():
                                + ("logits for every token" if args.all_logits else "n_outputs = 1 as llama-bench runs it (last layer's FFN and the output projection on one row)"),
                    "n_prompt": args.n_prompt, "n_gen": args.n_gen, "n_outputs_pp": args.n_prompt if args.all_logits else 1,
                    "parallelism": "single GPU" if world == 1 else f"ggml row split over {world} GPUs, RCCL all-gather concat",
-                   "tg_launch": "hipGraph replay" if graph is not None else "eager"},
+                   "tg_launch": "hipGraph replay" if graph is not None else "eager",
+                   "weight_layout": "GGUF wire" if args.wire_layout else "planar rows for Q4_0 / Q8_0 / Q6_K (in-place repack at upload, SURVEY 8f-2), GGUF wire otherwise"},
         "tg128_tok_s": round(tg_tok_s, 2), "pp512_tok_s": round(pp_tok_s, 2),
         "tg_ms_per_token": round(tg_s / args.n_gen * 1e3, 4), "pp_ms_per_batch": round(pp_s * 1e3, 3),
         "tg_algo_GBs": round(wl.algo_bytes(1) / world / (tg_s / args.n_gen) / 1e9, 1),

@@ -51,9 +51,17 @@ struct mi355x_device_ctx {
     qmm_event * ev_ready = nullptr;      // (as root) src1 is ready on the root's stream
 };
 
+// SURVEY 8f-2, weight repack: Q4_0 / Q8_0 / Q6_K weight tensors are re-laid into aligned planes (qmm_repack_rows) the first time
+// a MUL_MAT / MUL_MAT_ID reads them, in place, row by row: sizes and strides do not change, so nothing of ggml-alloc's view moves.
+// (The AMX buffer type converts inside set_tensor and has no get_tensor, ggml/src/ggml-cpu/amx/amx.cpp; here llama.cpp's pipelined
+// loader writes tensors in arbitrary byte chunks, so the conversion waits for the first use instead, and get_tensor, cpy_tensor and
+// partial writes convert a tensor BACK to GGUF wire layout first: what leaves the buffer is always wire bytes.)
+struct planar_rec { int wire_type; int64_t K, rows, row_bytes; size_t bytes; };
 struct mi355x_buffer_ctx {
     mi355x_device_ctx * dev;
     void *              base;
+    std::mutex                          mu;
+    std::map<const char *, planar_rec>  planar;     // by the tensor's first byte
 };
 
 struct mi355x_backend_ctx {
@@ -102,6 +110,10 @@ bool GGML_MI355X_CHAIN() {
     static const bool on = [] { const char * e = getenv("GGML_MI355X_CHAIN"); return e && atoi(e) != 0; }();
     return on;
 }
+bool GGML_MI355X_REPACK() {
+    static const bool on = [] { const char * e = getenv("GGML_MI355X_REPACK"); return !(e && atoi(e) == 0); }();
+    return on;
+}
 bool GGML_MI355X_FUSE_OFF() {
     static const bool off = [] { const char * e = getenv("GGML_MI355X_FUSE"); return e && atoi(e) == 0; }();
     return off;
@@ -118,6 +130,64 @@ bool type_supported(enum ggml_type t) {
            t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_IQ4_NL;
 }
 
+
+// ----------------------------------------------------------------------------------------------- planar weights
+
+// every planar tensor that overlaps [p, p + size) goes back to wire layout (unless the range covers it and `overwritten`)
+void planar_release(mi355x_buffer_ctx * bc, const char * p, size_t size, bool overwritten, void * stream) {
+    std::lock_guard<std::mutex> lock(bc->mu);
+    for (auto it = bc->planar.begin(); it != bc->planar.end();) {
+        const char * t0 = it->first;
+        const planar_rec & r = it->second;
+        if (t0 < p + size && p < t0 + r.bytes) {
+            const bool covered = overwritten && p <= t0 && t0 + r.bytes <= p + size;
+            if (!covered) {
+                if (qmm_repack_rows(bc->dev->qmm, r.wire_type, (void *) t0, r.row_bytes, r.rows, r.K, 0, stream) || qmm_synchronize(bc->dev->qmm, stream))
+                    GGML_ABORT("MI355X: converting a planar weight back to wire layout failed: %s", qmm_last_error());
+            }
+            it = bc->planar.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+const char * buft_get_name(ggml_backend_buffer_type_t buft);
+// the tensor's buffer context when it lives in an ordinary (not split, not host) MI355X buffer
+mi355x_buffer_ctx * our_buffer_ctx(const ggml_tensor * t) {
+    ggml_backend_buffer_t b = t->view_src ? t->view_src->buffer : t->buffer;
+    return b && b->buft->iface.get_name == buft_get_name ? (mi355x_buffer_ctx *) b->context : nullptr;
+}
+// type code for the kernel library: the planar code when the tensor's rows are in planar form (views: same rows as the root)
+int dev_type(const ggml_tensor * t) {
+    const ggml_tensor * root = t->view_src ? t->view_src : t;
+    if (root->type != GGML_TYPE_Q4_0 && root->type != GGML_TYPE_Q8_0 && root->type != GGML_TYPE_Q6_K) return (int) t->type;
+    mi355x_buffer_ctx * bc = our_buffer_ctx(root);
+    if (!bc) return (int) t->type;
+    std::lock_guard<std::mutex> lock(bc->mu);
+    auto it = bc->planar.find((const char *) root->data);
+    if (it == bc->planar.end()) return (int) t->type;
+    GGML_ASSERT(t->ne[0] == root->ne[0] && t->nb[1] == root->nb[1] && "a view that cuts rows of a planar weight");
+    return (int) t->type + 100;
+}
+// first use as a MUL_MAT / MUL_MAT_ID weight: convert the whole (root) tensor, on the compute stream, in front of the launch
+int weight_type(mi355x_backend_ctx * ctx, const ggml_tensor * t) {
+    const ggml_tensor * root = t->view_src ? t->view_src : t;
+    mi355x_buffer_ctx * bc = GGML_MI355X_REPACK() ? our_buffer_ctx(root) : nullptr;
+    const int pt = bc ? qmm_planar_type((int) root->type, root->ne[0], (int64_t) root->nb[1]) : 0;
+    if (!pt || !ggml_is_contiguous(root) || (uintptr_t) root->data % 16 || t->ne[0] != root->ne[0] || t->nb[1] != root->nb[1]) return dev_type(t);
+    {
+        std::lock_guard<std::mutex> lock(bc->mu);
+        if (bc->planar.count((const char *) root->data)) return pt;
+        const int64_t rows = ggml_nrows(root);
+        if (qmm_repack_rows(ctx->dev->qmm, (int) root->type, root->data, (int64_t) root->nb[1], rows, root->ne[0], 1, qmm_stream(ctx->dev->qmm))) {
+            GGML_LOG_WARN("MI355X: repack of %s refused (%s); it stays in wire layout\n", root->name, qmm_last_error());
+            return (int) t->type;
+        }
+        bc->planar[(const char *) root->data] = planar_rec{ (int) root->type, root->ne[0], rows, (int64_t) root->nb[1], ggml_nbytes(root) };
+    }
+    return pt;
+}
+
 // ----------------------------------------------------------------------------------------------- buffer
 
 void buffer_free(ggml_backend_buffer_t buffer) {
@@ -131,16 +201,19 @@ enum ggml_status buffer_init_tensor(ggml_backend_buffer_t, struct ggml_tensor *)
 
 void buffer_memset_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    planar_release(ctx, (const char *) tensor->data + offset, size, true, nullptr);
     if (qmm_memset(ctx->dev->qmm, (char *) tensor->data + offset, value, size, nullptr) || qmm_synchronize(ctx->dev->qmm, nullptr))
         GGML_ABORT("MI355X memset_tensor: %s", qmm_last_error());
 }
 void buffer_set_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    planar_release(ctx, (const char *) tensor->data + offset, size, true, nullptr);       // wire bytes come in: the tensor is wire again
     if (qmm_memcpy_h2d(ctx->dev->qmm, (char *) tensor->data + offset, data, size, nullptr))
         GGML_ABORT("MI355X set_tensor: %s", qmm_last_error());
 }
 void buffer_get_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    planar_release(ctx, (const char *) tensor->data + offset, size, false, nullptr);      // wire bytes go out (converted again at the next use)
     if (qmm_memcpy_d2h(ctx->dev->qmm, data, (const char *) tensor->data + offset, size, nullptr))
         GGML_ABORT("MI355X get_tensor: %s", qmm_last_error());
 }
@@ -151,12 +224,15 @@ bool buffer_cpy_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * 
     if (!sb || sb->buft->iface.get_name != buft_get_name) return false;           // not one of ours: let ggml stage through the host
     auto * sctx = (mi355x_buffer_ctx *) sb->context;
     if (sctx->dev != ctx->dev) return false;
+    planar_release(sctx, (const char *) src->data, ggml_nbytes(src), false, nullptr);
+    planar_release(ctx, (const char *) dst->data, ggml_nbytes(src), true, nullptr);
     if (qmm_memcpy_d2d(ctx->dev->qmm, dst->data, src->data, ggml_nbytes(src), nullptr) || qmm_synchronize(ctx->dev->qmm, nullptr))
         GGML_ABORT("MI355X cpy_tensor: %s", qmm_last_error());
     return true;
 }
 void buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    { std::lock_guard<std::mutex> lock(ctx->mu); ctx->planar.clear(); }
     if (qmm_memset(ctx->dev->qmm, ctx->base, value, buffer->size, nullptr) || qmm_synchronize(ctx->dev->qmm, nullptr))
         GGML_ABORT("MI355X clear: %s", qmm_last_error());
 }
@@ -184,7 +260,10 @@ ggml_backend_buffer_t buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t 
         GGML_LOG_ERROR("%s: allocating %.2f MiB on %s failed: %s\n", __func__, size / 1048576.0, dev->name.c_str(), qmm_last_error());
         return nullptr;
     }
-    return ggml_backend_buffer_init(buft, buffer_iface, new mi355x_buffer_ctx{ dev, p }, size);
+    auto * bc = new mi355x_buffer_ctx;
+    bc->dev = dev;
+    bc->base = p;
+    return ggml_backend_buffer_init(buft, buffer_iface, bc, size);
 }
 size_t buft_get_alignment(ggml_backend_buffer_type_t) { return 256; }
 size_t buft_get_max_size(ggml_backend_buffer_type_t buft) {
@@ -514,7 +593,7 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
         // nodes and hoists a later MUL_MAT when that is safe (can_hoist).
         qmm_weight ws[4];
         int n = 0, member[4] = { 0, 0, 0, 0 };                                 // node index (relative) of every matrix of the group
-        ws[n++] = qmm_weight{ a->data, (int64_t) a->nb[1], a->ne[1], (float *) dst->data, (int64_t) (dst->nb[1] / sizeof(float)), (int) a->type };
+        ws[n++] = qmm_weight{ a->data, (int64_t) a->nb[1], a->ne[1], (float *) dst->data, (int64_t) (dst->nb[1] / sizeof(float)), weight_type(ctx, a) };
         std::vector<const ggml_tensor *> & skipped = ctx->skipped;
         skipped.clear();
         for (int i = 1; i < n_nodes && i <= LOOKAHEAD && n < 4 && !GGML_MI355X_FUSE_OFF(); ++i) {
@@ -527,7 +606,7 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
                 if (!can_hoist(d, skipped)) out = (float *) hoist_elsewhere(ctx, d);   // its block is still in use here: compute into scratch
                 if (out) {
                     member[n] = i;
-                    ws[n++] = qmm_weight{ w->data, (int64_t) w->nb[1], w->ne[1], out, (int64_t) (d->nb[1] / sizeof(float)), (int) w->type };
+                    ws[n++] = qmm_weight{ w->data, (int64_t) w->nb[1], w->ne[1], out, (int64_t) (d->nb[1] / sizeof(float)), weight_type(ctx, w) };
                     done[i] = 1;
                     continue;
                 }
@@ -625,7 +704,7 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
             const char * wp = (const char *) a->data + (i12 / r2) * a->nb[2] + (i13 / r3) * a->nb[3];
             const char * xp = (const char *) b->data + i12 * b->nb[2] + i13 * b->nb[3];
             char * dp = (char *) dst->data + i12 * dst->nb[2] + i13 * dst->nb[3];
-            if (qmm_mul_mat(q, a->type, wp, a->nb[1], K, a->ne[1], (const float *) xp, N, b->nb[1] / sizeof(float),
+            if (qmm_mul_mat(q, weight_type(ctx, a), wp, a->nb[1], K, a->ne[1], (const float *) xp, N, b->nb[1] / sizeof(float),
                             (float *) dp, dst->nb[1] / sizeof(float), st)) {
                 GGML_LOG_ERROR("MI355X MUL_MAT(%s): %s\n", dst->name, qmm_last_error());
                 return GGML_STATUS_FAILED;
@@ -660,7 +739,9 @@ enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, ggml_tensor * cons
     }
     if (twin) {
         const ggml_tensor * dst1 = nodes[twin];
-        if (qmm_mul_mat_id_pair(q, as->type, as->data, dst1->src[0]->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
+        const int t0 = weight_type(ctx, as), t1 = weight_type(ctx, dst1->src[0]);
+        if (t0 != t1) { GGML_LOG_ERROR("MI355X MUL_MAT_ID pair: layouts differ\n"); return GGML_STATUS_FAILED; }
+        if (qmm_mul_mat_id_pair(q, t0, as->data, dst1->src[0]->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
                                 (const float *) b->data, b->ne[1], b->nb[1], b->nb[2],
                                 (const int32_t *) ids->data, ids->ne[0], ids->ne[1], ids->nb[1],
                                 (float *) dst->data, (float *) dst1->data, dst->nb[1], dst->nb[2], qmm_stream(q))) {
@@ -670,7 +751,7 @@ enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, ggml_tensor * cons
         done[twin] = 1;
         return GGML_STATUS_SUCCESS;
     }
-    if (qmm_mul_mat_id(q, as->type, as->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
+    if (qmm_mul_mat_id(q, weight_type(ctx, as), as->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
                        (const float *) b->data, b->ne[1], b->nb[1], b->nb[2],
                        (const int32_t *) ids->data, ids->ne[0], ids->ne[1], ids->nb[1],
                        (float *) dst->data, dst->nb[1], dst->nb[2], qmm_stream(q))) {
@@ -692,7 +773,7 @@ qmm_tensor to_qt(const ggml_tensor * t, const mi355x_backend_ctx * ctx) {
         for (const auto & r : ctx->redirects)
             if (r.t == root) q.data = r.data + ((const char *) t->data - (const char *) root->data);
     }
-    q.type = (int32_t) t->type;
+    q.type = (int32_t) dev_type(t);
     for (int i = 0; i < 4; ++i) { q.ne[i] = t->ne[i]; q.nb[i] = (int64_t) t->nb[i]; }
     memcpy(q.op_params, t->op_params, sizeof(q.op_params));
     return q;
@@ -805,12 +886,14 @@ bool on_device(const struct ggml_tensor * t, const mi355x_device_ctx * dev) {
 void backend_set_tensor_async(ggml_backend_t backend, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     GGML_ASSERT(on_device(tensor, ctx->dev) && "set_tensor_async: tensor is not in this device's buffer type");
+    if (mi355x_buffer_ctx * bc = our_buffer_ctx(tensor)) planar_release(bc, (const char *) tensor->data + offset, size, true, qmm_stream(ctx->dev->qmm));
     if (qmm_memcpy_h2d_async(ctx->dev->qmm, (char *) tensor->data + offset, data, size, qmm_stream(ctx->dev->qmm)))
         GGML_ABORT("MI355X set_tensor_async: %s", qmm_last_error());
 }
 void backend_get_tensor_async(ggml_backend_t backend, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     GGML_ASSERT(on_device(tensor, ctx->dev) && "get_tensor_async: tensor is not in this device's buffer type");
+    if (mi355x_buffer_ctx * bc = our_buffer_ctx(tensor)) planar_release(bc, (const char *) tensor->data + offset, size, false, qmm_stream(ctx->dev->qmm));
     if (qmm_memcpy_d2h_async(ctx->dev->qmm, data, (const char *) tensor->data + offset, size, qmm_stream(ctx->dev->qmm)))
         GGML_ABORT("MI355X get_tensor_async: %s", qmm_last_error());
 }
@@ -820,6 +903,8 @@ bool backend_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backend
     auto * sctx = (mi355x_backend_ctx *) backend_src->context;
     auto * dctx = (mi355x_backend_ctx *) backend_dst->context;
     if (!on_device(src, sctx->dev) || !on_device(dst, dctx->dev) || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst)) return false;
+    if (mi355x_buffer_ctx * bc = our_buffer_ctx(src)) planar_release(bc, (const char *) src->data, ggml_nbytes(src), false, qmm_stream(sctx->dev->qmm));
+    if (mi355x_buffer_ctx * bc = our_buffer_ctx(dst)) planar_release(bc, (const char *) dst->data, ggml_nbytes(src), true, qmm_stream(dctx->dev->qmm));
     qmm_ctx * dq = dctx->dev->qmm;
     void * dst_stream = qmm_stream(dq);
     if (sctx->dev != dctx->dev) {            // the copy runs on the destination's stream, behind what the source has queued
@@ -1249,7 +1334,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
             const ggml_tensor * w = node->src[0];
             const auto & sg = ctx->swiglu_in[i];
             st = GGML_STATUS_SUCCESS;
-            if (qmm_mul_mat_swiglu_in(ctx->dev->qmm, w->type, w->data, w->nb[1], w->ne[0], w->ne[1], sg.gate, sg.ld_gate, sg.up, sg.ld_up,
+            if (qmm_mul_mat_swiglu_in(ctx->dev->qmm, weight_type(ctx, w), w->data, w->nb[1], w->ne[0], w->ne[1], sg.gate, sg.ld_gate, sg.up, sg.ld_up,
                                       node->src[1]->ne[1], (float *) node->data, node->nb[1] / sizeof(float), qmm_stream(ctx->dev->qmm))) {
                 GGML_LOG_ERROR("MI355X MUL_MAT(%s) with SwiGLU input: %s\n", node->name, qmm_last_error());
                 st = GGML_STATUS_FAILED;

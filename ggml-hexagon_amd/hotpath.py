@@ -17,9 +17,11 @@ from .workload import Workload
 
 
 class HotPath:
-    def __init__(self, qmm, wl: Workload, device, rank: int = 0, world: int = 1, concat=None, seed: int = 1234):
+    def __init__(self, qmm, wl: Workload, device, rank: int = 0, world: int = 1, concat=None, seed: int = 1234, planar: bool = True):
         self.q, self.wl, self.dev, self.rank, self.world, self.concat = qmm, wl, device, rank, world, concat
         self.weights = {}       # name -> (uint8 tensor [rows, row_bytes] | [n_expert, M, row_bytes], ranges)
+        self.types = {}         # name -> type code for the C-ABI: the planar code where the rows were re-laid, as the
+        #                         plugin does with Q4_0 / Q8_0 / Q6_K weights at their first use; same bytes, same results
         i = 0
         for g in wl.groups:
             for m in g.mats:
@@ -29,13 +31,20 @@ class HotPath:
                         raise RuntimeError("MUL_MAT_ID workloads are not row-split; run with --gpus 1")
                     w = synth.synth_weights_torch(m.type, m.n_expert * m.M, m.K, device, seed + i).reshape(m.n_expert, m.M, -1)
                     self.weights[m.name] = (w, None)
+                    self.types[m.name] = self._layout(m.type, w, m.K, planar)
                 else:
                     ranges = rowsplit.all_ranges(m.M, world)
                     lo, hi = ranges[rank]
                     w = synth.synth_weights_torch(m.type, hi - lo, m.K, device, seed + 1000 * rank + i)
                     self.weights[m.name] = (w, ranges)
+                    self.types[m.name] = self._layout(m.type, w, m.K, planar)
         self.io = {}
         self.chain = False       # persistent chains for token generation (bench.py --chain): measured slower than launches, DESIGN.md
+
+    def _layout(self, t, w, k, planar):
+        if planar and w.numel() and self.q.planar_type(t, k, w.stride(-2)):
+            return self.q.repack_rows(t, w, k, True)
+        return t
 
     def weight_bytes_local(self) -> int:
         return sum(w.numel() for w, _ in self.weights.values())
@@ -100,17 +109,17 @@ class HotPath:
                 ne11 = m0.n_used if m0.name.endswith("down_exps") else 1
                 outs = [dst_local[("id", m.name.split(".")[-1], m.M)] for m in grp.mats]
                 if len(grp.mats) == 2 and grp.mats[1].type == m0.type:      # ffn_gate_exps + ffn_up_exps: same b, same ids
-                    q.mul_mat_id_pair(m0.type, self.weights[grp.mats[0].name][0], self.weights[grp.mats[1].name][0], m0.K,
+                    q.mul_mat_id_pair(self.types[m0.name], self.weights[grp.mats[0].name][0], self.weights[grp.mats[1].name][0], m0.K,
                                       x[(m0.K, ne11)], ids[:, :m0.n_used], outs[0], outs[1])
                 else:
                     for m, o in zip(grp.mats, outs):
-                        q.mul_mat_id(m.type, self.weights[m.name][0], m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=o)
+                        q.mul_mat_id(self.types[m.name], self.weights[m.name][0], m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=o)
                 continue
             ws, outs, keys = [], [], []
             for m in grp.mats:
                 w, ranges = self.weights[m.name]
                 dkey = (m.name.split(".")[-1], w.shape[0])
-                ws.append((m.type, w))
+                ws.append((self.types[m.name], w))
                 outs.append(dst_local[dkey])
                 keys.append((dkey, ranges))
             q.mul_mat_group(ws, m0.K, x[m0.K], outs)

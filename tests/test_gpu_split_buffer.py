@@ -56,3 +56,22 @@ def test_moe_twin_nodes_go_out_as_one_call():
     out = p.stdout + p.stderr
     m = re.search(r"(\d+) OK, (\d+) FAILED", out)
     assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) >= 18, out[-3000:]
+
+
+def test_planar_weights_through_the_plugin():
+    """SURVEY 8f-2 (tests/cpp/test_planar_weights.cpp): lazily repacked Q4_0 / Q8_0 / Q6_K weights behave like wire tensors for
+    get_tensor / partial set_tensor / tensor copies, match the CPU backend, and give the bits of the un-repacked build"""
+    exe = ROOT / "oracle" / "_ref" / "test-planar-weights"
+    if not exe.exists() or not PLUGIN.exists():
+        pytest.skip("oracle/_ref/test-planar-weights or the plugin module is not built (needs the reference tree at build time)")
+    sums = {}
+    for repack in ("1", "0"):
+        env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN), GGML_MI355X_REPACK=repack)
+        p = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=600, cwd=str(exe.parent))
+        out = p.stdout + p.stderr
+        fails = [l for l in out.splitlines() if l.rstrip().endswith("FAIL")]
+        assert not fails, "\n".join(fails[:20])
+        m = re.search(r"(\d+) OK, (\d+) FAILED", out)
+        assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) == 40, out[-3000:]
+        sums[repack] = re.search(r"checksum ([0-9a-f]+)", out).group(1)
+    assert sums["1"] == sums["0"], sums

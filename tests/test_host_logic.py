@@ -143,6 +143,9 @@ class _OracleQmm:
         from oracle.pyoracle import Oracle
         self.o = Oracle()
 
+    def planar_type(self, t, k, row_bytes):      # the CPU stand-in keeps GGUF wire layout (the planar repack is a device matter)
+        return 0
+
     def mul_mat_group(self, weights, k, x, outs):
         import torch
         for (t, w), out in zip(weights, outs):
