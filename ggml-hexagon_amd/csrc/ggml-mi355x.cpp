@@ -114,10 +114,12 @@ bool GGML_MI355X_REPACK() {
     static const bool on = [] { const char * e = getenv("GGML_MI355X_REPACK"); return !(e && atoi(e) == 0); }();
     return on;
 }
+int g_fuse_override = -1;            // -1: the environment decides; 0 / 1: set through the "ggml_backend_mi355x_set_fuse" proc address (tests)
 bool GGML_MI355X_FUSE_OFF() {
     static const bool off = [] { const char * e = getenv("GGML_MI355X_FUSE"); return e && atoi(e) == 0; }();
-    return off;
+    return g_fuse_override >= 0 ? g_fuse_override == 0 : off;
 }
+void set_fuse(int on) { g_fuse_override = on < 0 ? -1 : on != 0; }
 
 mi355x_device_ctx      g_devs[GGML_MI355X_MAX_DEVICES];
 ggml_backend_device    g_devices[GGML_MI355X_MAX_DEVICES];
@@ -535,6 +537,24 @@ bool ranges_overlap(const ggml_tensor * x, const ggml_tensor * y) {
     const char * x0 = (const char *) x->data, * y0 = (const char *) y->data;
     return x0 < y0 + ggml_nbytes(y) && y0 < x0 + ggml_nbytes(x);
 }
+bool dbg();
+bool bytes_overlap(const void * a, size_t an, const void * b, size_t bn) {
+    const char * a0 = (const char *) a, * b0 = (const char *) b;
+    return a && b && a0 < b0 + bn && b0 < a0 + an;
+}
+// A fused launch writes the buffer of a LATER node (`late`) at the position of an earlier one.  ggml-alloc may have given `late` a
+// block that was freed once the earlier nodes' operands were dead, i.e. exactly the memory the launch still reads: other workgroups
+// would overwrite it while it is being staged.  Legal only when `late` is disjoint from every operand (an operand at the very same
+// address with the same row layout is fine where the launch reads an element before the same thread writes it: `inplace_ok`).
+bool early_write_ok(const ggml_tensor * late, std::initializer_list<const ggml_tensor *> operands, const ggml_tensor * inplace_ok = nullptr) {
+    for (const ggml_tensor * o : operands) {
+        if (!o || !ranges_overlap(late, o)) continue;
+        if (o == inplace_ok && o->data == late->data && o->nb[1] == late->nb[1] && ggml_are_same_shape(o, late)) continue;
+        if (dbg()) fprintf(stderr, "fusion declined: %s would be written early over %s\n", late->name, o->name);
+        return false;
+    }
+    return true;
+}
 // may `t` run before the nodes in `skipped` although the graph lists it after them?  Its operands are ready (the caller
 // checked), so the question is memory: ggml-alloc reuses freed blocks, so t's result must not land on anything a skipped
 // node still reads or writes.
@@ -623,7 +643,12 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
         if (ctx->pending_norm.mul == b) {
             const auto pn = ctx->pending_norm;
             ctx->pending_norm = {};
-            if (n == pn.readers) {
+            // the kernels read the un-normed row while they write their results: a result that ggml-alloc placed in the block of
+            // that row (dead once the norm has run, in the graph's order) would be overwritten under the staging of other workgroups
+            bool norm_in_kernel = n == pn.readers;
+            for (int i = 0; norm_in_kernel && i < n; ++i)
+                norm_in_kernel = !bytes_overlap(ws[i].dst, (size_t) ((N - 1) * ws[i].ldd + ws[i].M) * sizeof(float), to_qt(pn.rn->src[0], ctx).data, ggml_nbytes(pn.rn->src[0]));
+            if (norm_in_kernel) {
                 const qmm_tensor qx = to_qt(pn.rn->src[0], ctx);
                 x = (const float *) qx.data;
                 ldx = pn.rn->src[0]->nb[1] / sizeof(float);
@@ -659,7 +684,16 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
                     else break;
                 }
             }
-            if (jm >= 0 && uses(t0) == 1 && uses(t1) == 1 && uses(nodes[js]) == 1 && ggml_are_same_shape(nodes[jm], t0) && nodes[jm]->nb[0] == 4 &&
+            // the product lands in the MUL's buffer while the launch still stages x: that buffer must be disjoint from x and from
+            // everything the nodes in between (run later) still read or write
+            bool early_ok = jm >= 0 && !bytes_overlap(nodes[jm]->data, ggml_nbytes(nodes[jm]), x, (size_t) ((N - 1) * ldx + K) * sizeof(float));
+            for (int j = 1; early_ok && j < jm; ++j) {
+                if (done[j] || is_noop(nodes[j]) || j == js) continue;
+                early_ok = !ranges_overlap(nodes[jm], nodes[j]);
+                for (int k = 0; early_ok && k < GGML_MAX_SRC && nodes[j]->src[k]; ++k) early_ok = !ranges_overlap(nodes[jm], nodes[j]->src[k]);
+            }
+            if (jm >= 0 && !early_ok && dbg()) fprintf(stderr, "fusion declined: SwiGLU into %s\n", nodes[jm]->name);
+            if (jm >= 0 && early_ok && uses(t0) == 1 && uses(t1) == 1 && uses(nodes[js]) == 1 && ggml_are_same_shape(nodes[jm], t0) && nodes[jm]->nb[0] == 4 &&
                 !(nodes[jm]->flags & GGML_TENSOR_FLAG_OUTPUT) && !(t0->flags & GGML_TENSOR_FLAG_OUTPUT) && !(t1->flags & GGML_TENSOR_FLAG_OUTPUT) &&
                 (size_t) N * K * 5 / 4 + (ex.norm_w ? (size_t) N * K * 4 : 0) + 4096 <= 150 * 1024) {
                 ex.swiglu = nodes[js]->src[0] == t0 ? 1 : 2;
@@ -680,7 +714,13 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
             const bool single = it != ctx->readers.end() && it->t == dst && it->uses == 1;
             if (add && single && add->op == GGML_OP_ADD && (add->src[0] == dst || add->src[1] == dst) && add->src[0] != add->src[1]) {
                 const ggml_tensor * r = add->src[0] == dst ? add->src[1] : add->src[0];
-                if (ggml_are_same_shape(r, dst) && ggml_are_same_shape(add, dst) && r->type == GGML_TYPE_F32 && r->nb[0] == 4 && add->nb[0] == 4 &&
+                // dst = W x + r is written where the ADD would put it, while x is still being staged by other workgroups: the ADD's buffer must
+                // not be x's (ggml-alloc may hand the ADD the block of the dead src1), and r only where it is the very same rows (in place)
+                const qmm_tensor qr = to_qt(r, ctx);
+                const bool r_ok = !bytes_overlap(add->data, ggml_nbytes(add), qr.data, ggml_nbytes(r)) || (qr.data == add->data && r->nb[1] == add->nb[1]);
+                const bool x_ok = !bytes_overlap(add->data, ggml_nbytes(add), x, (size_t) ((N - 1) * ldx + K) * sizeof(float));
+                if ((!r_ok || !x_ok) && dbg()) fprintf(stderr, "fusion declined: residual into %s\n", add->name);
+                if (r_ok && x_ok && ggml_are_same_shape(r, dst) && ggml_are_same_shape(add, dst) && r->type == GGML_TYPE_F32 && r->nb[0] == 4 && add->nb[0] == 4 &&
                     r->nb[1] == add->nb[1] && add->nb[1] % 4 == 0) {
                     ex.residual[0] = (const float *) to_qt(r, ctx).data;
                     ws[0].dst = (float *) add->data;
@@ -1051,7 +1091,12 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                 ggml_tensor * rn = cgraph->nodes[i + 1], * mul = cgraph->nodes[i + 2];
                 if (rn->op == GGML_OP_RMS_NORM && rn->src[0] == node && single_use(rn) && fused_pair(rn, mul, &other) == QMM_OP_RMS_NORM_MUL) {
                     const qmm_tensor a = to_qt(node->src[0], ctx), b = to_qt(node->src[1], ctx), w = to_qt(other, ctx), sum = to_qt(node, ctx), d = to_qt(mul, ctx);
-                    if (qmm_op_add_rms_norm_supported(&a, &b, &w, &sum, &d)) {
+                    // `mul`'s buffer is written two nodes early: it may be the block of an ADD operand that dies here (same rows: fine, a
+                    // workgroup holds its row in registers before it stores; anything else: keep the graph's order)
+                    const bool e_ok = early_write_ok(mul, { node->src[0], node->src[1], other, node }, nullptr) ||
+                                      (early_write_ok(mul, { node->src[1], other, node }, nullptr) && early_write_ok(mul, { node->src[0] }, node->src[0])) ||
+                                      (early_write_ok(mul, { node->src[0], other, node }, nullptr) && early_write_ok(mul, { node->src[1] }, node->src[1]));
+                    if (e_ok && qmm_op_add_rms_norm_supported(&a, &b, &w, &sum, &d)) {
                         float eps;
                         memcpy(&eps, rn->op_params, sizeof(float));
                         if (qmm_op_add_rms_norm(ctx->dev->qmm, &a, &b, &w, &sum, &d, eps, qmm_stream(ctx->dev->qmm))) {
@@ -1080,7 +1125,8 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                     if (sm->op == GGML_OP_SOFT_MAX && sm->src[0] == node && sm->src[1] && max_bias == 0.0f && single_use(sm) &&
                         kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm && kqv->src[0]->type == GGML_TYPE_F16 && single_use(kqv) &&
                         pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv && pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] &&
-                        pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm) {
+                        pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm &&
+                        early_write_ok(ct, { node->src[1], node->src[0], kqv->src[0], sm->src[1] })) {
                         const qmm_tensor q = to_qt(node->src[1], ctx), kk = to_qt(node->src[0], ctx), v = to_qt(kqv->src[0], ctx), m = to_qt(sm->src[1], ctx), d = to_qt(ct, ctx);
                         const bool few = qmm_attn_decode_supported(&q, &kk, &v, &m, &d) != 0;
                         if (few || qmm_attn_prefill_supported(&q, &kk, &v, &m, &d)) {
@@ -1106,7 +1152,8 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                     const ggml_tensor * pm = cgraph->nodes[jp], * ct = cgraph->nodes[jc];
                     if (pm->op == GGML_OP_PERMUTE && pm->src[0] == node && ct->op == GGML_OP_CONT && ct->src[0] == pm && !done[jc] &&
                         pm->ne[0] == node->ne[0] && pm->ne[1] == node->ne[2] && pm->ne[2] == node->ne[1] && node->ne[3] == 1 &&
-                        ct->type == GGML_TYPE_F32 && ggml_is_contiguous(ct) && ggml_nelements(ct) == ggml_nelements(node)) {
+                        ct->type == GGML_TYPE_F32 && ggml_is_contiguous(ct) && ggml_nelements(ct) == ggml_nelements(node) &&
+                        early_write_ok(ct, { node->src[0], node->src[1] })) {
                         qmm_tensor d = to_qt(node, ctx);
                         d.data = ct->data;                                            // element (d, n, h) of kqv = element (d, h, n) of the merged result
                         d.nb[1] = (int64_t) node->ne[0] * node->ne[2] * 4;
@@ -1262,7 +1309,9 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                                 kqn->src[1]->src[0] == node && single_use(kqn) && sm->op == GGML_OP_SOFT_MAX && sm->src[0] == kqn && sm->src[1] &&
                                 max_bias == 0.0f && single_use(sm) && kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm &&
                                 kqv->src[0]->type == GGML_TYPE_F16 && single_use(kqv) && pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv &&
-                                pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] && pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm) {
+                                pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] && pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm &&
+                                early_write_ok(ct, { node->src[0], node->src[1], node->src[2], node, cgraph->nodes[jk]->src[0], cgraph->nodes[jcv]->src[0],
+                                                     kqn->src[0], kqv->src[0], sm->src[1] })) {
                                 const qmm_tensor kc = to_qt(kqn->src[0], ctx), vc = to_qt(kqv->src[0], ctx), m = to_qt(sm->src[1], ctx), d = to_qt(ct, ctx);
                                 const int64_t off = (const char *) kd.data - (const char *) kc.data;
                                 const int64_t j0 = kc.nb[1] > 0 && off >= 0 && off % kc.nb[1] == 0 ? off / kc.nb[1] : -1;
@@ -1319,6 +1368,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                     continue;
                 }
             }
+            if (fop && !(early_write_ok(cgraph->nodes[i + 1], { other }) && early_write_ok(cgraph->nodes[i + 1], { node->src[0] }, node->src[0]))) fop = 0;
             if (fop) {
                 ggml_tensor * out = cgraph->nodes[i + 1];
                 ggml_tensor tmp = *out;                                              // dst of the pair, carrying the first node's op_params (eps)
@@ -1504,6 +1554,9 @@ ggml_backend_buffer_type_t split_buffer_type(int main_device, const float * tens
 
 void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (strcmp(name, "ggml_backend_split_buffer_type") == 0) return (void *) split_buffer_type;    // llama.cpp -sm row
+    // void (*)(int on): multi-node launches on (1) / one launch per node (0) / back to GGML_MI355X_FUSE (-1); lets one process
+    // compare both schedules of the same graph (tests/cpp/test_graph_fuzz.cpp)
+    if (strcmp(name, "ggml_backend_mi355x_set_fuse") == 0) return (void *) set_fuse;
     return nullptr;
 }
 

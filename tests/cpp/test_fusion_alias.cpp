@@ -1,0 +1,148 @@
+// test_fusion_alias.cpp — the aliasing cases behind the plugin's multi-node launches (csrc/ggml-mi355x.cpp early_write_ok).
+// A fused launch writes a LATER node's buffer at an EARLIER point.  ggml-alloc may legally give that later node the block of a tensor
+// that is dead by then in the graph's order but is still an OPERAND of the fused launch: the residual ADD behind wo placed on wo's
+// src1, the SwiGLU product placed on ffn_norm's output, q placed on the un-normed row whose norm the mat-vec forms itself, the
+// merged-heads CONT placed on the soft-max output.  Here those placements are FORCED (ggml_backend_tensor_alloc at chosen addresses),
+// for 1, 4 and 40 tokens, and the results are compared with the CPU backend computing the same placements node by node
+// (NMSE <= 5e-4 per output; the fusion must either be safe or be declined).  Public ggml API only; GGML_BACKEND_PATH=<module>.
+#include "ggml.h"
+#include "ggml-alloc.h"
+#include "ggml-backend.h"
+#include "ggml-cpu.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <string>
+#include <vector>
+
+static int n_ok = 0, n_fail = 0;
+struct Placed { ggml_tensor * t; size_t off; };
+
+struct Graph {
+    ggml_context * ctx = nullptr;
+    std::vector<Placed> place;                       // every non-view tensor and its byte offset in the one buffer
+    std::vector<ggml_tensor *> views;
+    std::vector<std::pair<ggml_tensor *, std::vector<uint8_t>>> init;
+    std::vector<ggml_tensor *> outs;
+    size_t top = 0;
+    size_t fresh(ggml_tensor * t) { const size_t o = top; place.push_back({ t, o }); top += (ggml_nbytes(t) + 255) & ~(size_t) 255; return o; }
+    void at(ggml_tensor * t, size_t off) { place.push_back({ t, off }); }
+};
+
+static std::vector<std::vector<float>> run(ggml_backend_t be, const std::function<void(Graph &, std::mt19937 &)> & build) {
+    Graph G;
+    ggml_init_params ip = { ggml_tensor_overhead() * 256 + ggml_graph_overhead(), nullptr, true };
+    G.ctx = ggml_init(ip);
+    std::mt19937 rng(99);
+    build(G, rng);
+    ggml_cgraph * g = ggml_new_graph(G.ctx);
+    for (ggml_tensor * o : G.outs) ggml_build_forward_expand(g, o);
+    ggml_backend_buffer_t buf = ggml_backend_alloc_buffer(be, G.top + 4096);
+    char * base = (char *) ggml_backend_buffer_get_base(buf);
+    for (auto & p : G.place) ggml_backend_tensor_alloc(buf, p.t, base + p.off);
+    for (int i = 0; i < ggml_graph_n_nodes(g); ++i) {                               // views: after their sources have addresses
+        ggml_tensor * t = ggml_graph_node(g, i);
+        if (t->view_src && !t->data) ggml_backend_view_init(t);
+    }
+    for (auto & in : G.init) ggml_backend_tensor_set(in.first, in.second.data(), 0, in.second.size());
+    if (ggml_backend_graph_compute(be, g) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); exit(2); }
+    std::vector<std::vector<float>> res;
+    for (ggml_tensor * o : G.outs) { std::vector<float> v(ggml_nelements(o)); ggml_backend_tensor_get(o, v.data(), 0, v.size() * 4); res.push_back(v); }
+    ggml_backend_buffer_free(buf);
+    ggml_free(G.ctx);
+    return res;
+}
+
+static ggml_tensor * weight(Graph & G, std::mt19937 & rng, ggml_type type, int64_t k, int64_t m, float sigma) {
+    ggml_tensor * t = ggml_new_tensor_2d(G.ctx, type, k, m);
+    std::uniform_real_distribution<float> u(-sigma, sigma);
+    std::vector<float> f((size_t) k * m);
+    for (auto & v : f) v = u(rng);
+    std::vector<uint8_t> q(ggml_row_size(type, k) * m);
+    if (type == GGML_TYPE_F32) memcpy(q.data(), f.data(), q.size());
+    else ggml_quantize_chunk(type, f.data(), q.data(), 0, m, k, nullptr);
+    G.fresh(t);
+    G.init.push_back({ t, q });
+    return t;
+}
+
+static void compare(const char * what, int64_t n, ggml_backend_t gpu, ggml_backend_t cpu, const std::function<void(Graph &, std::mt19937 &)> & build) {
+    const auto a = run(gpu, build), b = run(cpu, build);
+    bool ok = a.size() == b.size();
+    double worst = 0;
+    for (size_t j = 0; ok && j < a.size(); ++j) {
+        double num = 0, den = 0;
+        for (size_t i = 0; i < a[j].size(); ++i) { const double d = (double) a[j][i] - b[j][i]; num += d * d; den += (double) b[j][i] * b[j][i]; ok = ok && std::isfinite(a[j][i]); }
+        worst = std::max(worst, den > 0 ? num / den : num);
+    }
+    ok = ok && worst <= 5e-4;
+    printf("  %-58s N=%-3lld nmse %.1e : %s\n", what, (long long) n, worst, ok ? "OK" : "FAIL");
+    ok ? ++n_ok : ++n_fail;
+}
+
+int main() {
+    ggml_backend_load_all();
+    ggml_backend_reg_t reg = ggml_backend_reg_by_name("MI355X");
+    if (!reg) { fprintf(stderr, "MI355X backend not loaded (GGML_BACKEND_PATH?)\n"); return 2; }
+    ggml_backend_t gpu = ggml_backend_dev_init(ggml_backend_reg_dev_get(reg, 0), nullptr);
+    ggml_backend_t cpu = ggml_backend_init_by_type(GGML_BACKEND_DEVICE_TYPE_CPU, nullptr);
+    const int64_t E = 1024, F = 2048;
+    for (int64_t N : { (int64_t) 1, (int64_t) 4, (int64_t) 40 }) {
+        // 1. dst = W x + r with the ADD's buffer ON x (x is dead once wo has read it, in the graph's order)
+        compare("residual ADD placed on the MUL_MAT's src1", N, gpu, cpu, [&](Graph & G, std::mt19937 & rng) {
+            ggml_tensor * x = weight(G, rng, GGML_TYPE_F32, E, N, 1.0f), * r = weight(G, rng, GGML_TYPE_F32, E, N, 1.0f);
+            ggml_tensor * W = weight(G, rng, GGML_TYPE_Q4_K, E, E, 0.05f);
+            ggml_tensor * mm = ggml_mul_mat(G.ctx, W, x);  G.fresh(mm);
+            ggml_tensor * out = ggml_add(G.ctx, mm, r);    G.at(out, G.place[0].off);                 // == x
+            ggml_tensor * fin = ggml_scale(G.ctx, out, 1.0f);  G.fresh(fin);
+            G.outs = { fin };
+        });
+        // 2. SwiGLU product placed on the activations gate / up read
+        compare("silu(gate) * up placed on ffn_gate / ffn_up's src1", N, gpu, cpu, [&](Graph & G, std::mt19937 & rng) {
+            ggml_tensor * x = weight(G, rng, GGML_TYPE_F32, E, N, 1.0f);
+            ggml_tensor * big = weight(G, rng, GGML_TYPE_F32, F, N, 1.0f);                             // room behind x for an [F, N] result
+            ggml_tensor * Wg = weight(G, rng, GGML_TYPE_Q4_K, E, F, 0.05f), * Wu = weight(G, rng, GGML_TYPE_Q4_K, E, F, 0.05f);
+            ggml_tensor * gt = ggml_mul_mat(G.ctx, Wg, x);  G.fresh(gt);
+            ggml_tensor * sl = ggml_silu(G.ctx, gt);        G.fresh(sl);
+            ggml_tensor * up = ggml_mul_mat(G.ctx, Wu, x);  G.fresh(up);
+            ggml_tensor * pr = ggml_mul(G.ctx, sl, up);     G.at(pr, G.place[0].off);                  // starts at x, spills into `big`
+            ggml_tensor * Wd = weight(G, rng, GGML_TYPE_Q4_K, F, E, 0.05f);
+            ggml_tensor * dn = ggml_mul_mat(G.ctx, Wd, pr); G.fresh(dn);
+            (void) big;
+            G.outs = { dn };
+        });
+        // 3. q placed on the un-normed row (dead behind RMS_NORM * w), whose norm the mat-vec kernels form while staging
+        compare("wq's result placed on the input of the folded RMS_NORM", N, gpu, cpu, [&](Graph & G, std::mt19937 & rng) {
+            ggml_tensor * h = weight(G, rng, GGML_TYPE_F32, E, N, 1.0f);
+            ggml_tensor * nw = weight(G, rng, GGML_TYPE_F32, E, 1, 1.0f);
+            ggml_tensor * Wq = weight(G, rng, GGML_TYPE_Q4_K, E, E, 0.05f), * Wk = weight(G, rng, GGML_TYPE_Q4_K, E, 256, 0.05f);
+            ggml_tensor * rn = ggml_rms_norm(G.ctx, h, 1e-5f);  G.fresh(rn);
+            ggml_tensor * xn = ggml_mul(G.ctx, rn, nw);         G.fresh(xn);
+            ggml_tensor * q = ggml_mul_mat(G.ctx, Wq, xn);      G.at(q, G.place[0].off);              // == h
+            ggml_tensor * k = ggml_mul_mat(G.ctx, Wk, xn);      G.fresh(k);
+            ggml_tensor * fq = ggml_scale(G.ctx, q, 1.0f), * fk = ggml_scale(G.ctx, k, 1.0f);
+            G.fresh(fq); G.fresh(fk);
+            G.outs = { fq, fk };
+        });
+        // 4. ADD -> RMS_NORM -> MUL(w) as one launch with the MUL's buffer on an ADD operand, shifted by one row's worth of bytes
+        compare("normed row placed on an operand of the residual ADD", N, gpu, cpu, [&](Graph & G, std::mt19937 & rng) {
+            ggml_tensor * a = weight(G, rng, GGML_TYPE_F32, E, N + 1, 1.0f);                           // one spare row: the shifted result fits
+            ggml_tensor * b = weight(G, rng, GGML_TYPE_F32, E, N, 1.0f), * nw = weight(G, rng, GGML_TYPE_F32, E, 1, 1.0f);
+            ggml_tensor * av = ggml_view_2d(G.ctx, a, E, N, E * 4, 0);
+            ggml_tensor * sum = ggml_add(G.ctx, av, b);         G.fresh(sum);
+            ggml_tensor * rn = ggml_rms_norm(G.ctx, sum, 1e-5f);  G.fresh(rn);
+            ggml_tensor * xn = ggml_mul(G.ctx, rn, nw);         G.at(xn, G.place[0].off + (N > 1 ? E * 4 : 0));   // on a, one row further
+            ggml_tensor * f1 = ggml_scale(G.ctx, xn, 1.0f), * f2 = ggml_scale(G.ctx, sum, 1.0f);
+            G.fresh(f1); G.fresh(f2);
+            G.outs = { f1, f2 };
+        });
+    }
+    ggml_backend_free(gpu);
+    ggml_backend_free(cpu);
+    printf("%d OK, %d FAILED\n", n_ok, n_fail);
+    return n_fail ? 1 : 0;
+}

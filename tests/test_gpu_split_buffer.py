@@ -75,3 +75,34 @@ def test_planar_weights_through_the_plugin():
         assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) == 40, out[-3000:]
         sums[repack] = re.search(r"checksum ([0-9a-f]+)", out).group(1)
     assert sums["1"] == sums["0"], sums
+
+
+def test_graph_scheduler_on_random_transformer_graphs():
+    """tests/cpp/test_graph_fuzz.cpp: 60 random llama / qwen / gemma / gpt-neox style block graphs, allocated by ggml's own graph
+    allocator, fused schedule vs one launch per node vs the CPU backend"""
+    exe = ROOT / "oracle" / "_ref" / "test-graph-fuzz"
+    if not exe.exists() or not PLUGIN.exists():
+        pytest.skip("oracle/_ref/test-graph-fuzz or the plugin module is not built (needs the reference tree at build time)")
+    env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN))
+    p = subprocess.run([str(exe), "60"], env=env, capture_output=True, text=True, timeout=900, cwd=str(exe.parent))
+    out = p.stdout + p.stderr
+    print(out[-1500:])
+    fails = [l for l in out.splitlines() if l.rstrip().endswith("FAIL")]
+    assert not fails, "\n".join(fails[:20])
+    m = re.search(r"(\d+) OK, (\d+) FAILED", out)
+    assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) == 60, out[-3000:]
+
+
+def test_fusions_survive_forced_buffer_aliasing():
+    """tests/cpp/test_fusion_alias.cpp: a later node's buffer placed on an operand the fused launch still reads"""
+    exe = ROOT / "oracle" / "_ref" / "test-fusion-alias"
+    if not exe.exists() or not PLUGIN.exists():
+        pytest.skip("oracle/_ref/test-fusion-alias or the plugin module is not built (needs the reference tree at build time)")
+    env = dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN))
+    p = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=600, cwd=str(exe.parent))
+    out = p.stdout + p.stderr
+    print(out[-2500:])
+    fails = [l for l in out.splitlines() if l.rstrip().endswith("FAIL")]
+    assert not fails, "\n".join(fails[:20])
+    m = re.search(r"(\d+) OK, (\d+) FAILED", out)
+    assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) == 12, out[-3000:]
