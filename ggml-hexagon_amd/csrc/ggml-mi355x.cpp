@@ -583,7 +583,10 @@ void * hoist_elsewhere(mi355x_backend_ctx * ctx, const ggml_tensor * d) {
     if (it == ctx->readers.end() || it->t != d || !it->glue_only || it->uses == 0) return nullptr;
     const size_t bytes = (ggml_nbytes(d) + 255) & ~(size_t) 255;
     if (ctx->hoist_used + bytes > ctx->hoist_bytes) {
-        if (ctx->hoist_used || !ctx->redirects.empty()) return nullptr;                // live results in the old block: not this time
+        if (ctx->hoist_used || !ctx->redirects.empty()) {                              // live results in the old block: not this time
+            if (dbg()) fprintf(stderr, "hoist refused for %s: scratch exhausted (%zu of %zu bytes in use)\n", d->name, ctx->hoist_used, ctx->hoist_bytes);
+            return nullptr;
+        }
         if (!grow(ctx->dev, ctx->hoist_buf, ctx->hoist_bytes, std::max<size_t>((size_t) 64 << 20, 64 * bytes))) return nullptr;
     }
     char * p = (char *) ctx->hoist_buf + ctx->hoist_used;
@@ -1043,6 +1046,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         struct ggml_tensor * node = cgraph->nodes[i];
         if (done[i] || is_noop(node)) continue;                                      // ggml-hexagon.cpp:5561-5566
         while (!ctx->redirects.empty() && ctx->redirects.front().last_reader < i) ctx->redirects.erase(ctx->redirects.begin());
+        if (ctx->redirects.empty()) ctx->hoist_used = 0;       // nothing lives in the scratch any more: the next layer starts at its base again
         enum ggml_status st;
         const int gop = glue_op(node);
         if (gop) {

@@ -491,6 +491,17 @@ int qmm_synchronize(qmm_ctx * c, void * st) {
             return fail(QMM_EHIP, "chain: a grid-wide wait timed out (workgroups not co-resident?); results of that launch are undefined");
         }
     }
+    if (c->mfma_calls != c->mfma_checked) {                  // prefill launches since the last look: did the f16 mode overflow?
+        c->mfma_checked = c->mfma_calls;
+        int nf = 0;
+        HIP_TRY(hipMemcpyFromSymbol(&nf, HIP_SYMBOL(g_mfma_nonfinite), sizeof(int)));
+        if (nf) {
+            const int zero = 0;
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_nonfinite), &zero, sizeof(int)));
+            return fail(QMM_EUNSUPPORTED, "prefill (f16 on Q8 activations) produced non-finite values: a weight block exceeds the f16 range (|w| >= 65504) "
+                                          "or the activations are not finite; use QMM_PREC_BF16 (GGML_MI355X_PREC=bf16) for this model");
+        }
+    }
     int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
@@ -673,6 +684,7 @@ static int mul_mat_group_impl(qmm_ctx * c, const qmm_weight * ws, int nw, int64_
         }
         return QMM_OK;
     }
+    c->mfma_calls++;
     int last_key = -1;                   // the group shares src1: its 16-bit operand is prepared once per activation format
     for (int i = 0; i < nw;) {
         if (ws[i].M == 0) { ++i; continue; }
@@ -737,6 +749,7 @@ int qmm_mul_mat_id(qmm_ctx * c, int type, const void * as, int64_t rb, int64_t e
     if (n_tokens <= 0 || n_used <= 0 || M <= 0) return QMM_OK;
     HIP_TRY(hipSetDevice(c->device));
     QMM_CHAIN_FLUSH(c);
+    c->mfma_calls++;
     return moe_mul_mat_id(c, c->s(stream), type, as, rb, expert_bytes, K, M, n_expert, b, ne11, b_nb1, b_nb2,
                           ids, n_used, n_tokens, ids_nb1, dst, d_nb1, d_nb2);
 }
@@ -755,6 +768,7 @@ int qmm_mul_mat_id_pair(qmm_ctx * c, int type, const void * as0, const void * as
     if (n_tokens <= 0 || n_used <= 0 || M <= 0) return QMM_OK;
     HIP_TRY(hipSetDevice(c->device));
     QMM_CHAIN_FLUSH(c);
+    c->mfma_calls++;
     return moe_mul_mat_id(c, c->s(stream), type, as0, rb, expert_bytes, K, M, n_expert, b, ne11, b_nb1, b_nb2,
                           ids, n_used, n_tokens, ids_nb1, dst0, d_nb1, d_nb2, as1, dst1);
 }

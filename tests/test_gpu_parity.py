@@ -459,3 +459,32 @@ def test_bad_arguments_fail_loudly(qmm):
         qmm.mul_mat(Q8_K, w, k, x)                            # Q8_K is an activation format, not a weight type
     torch.cuda.synchronize()
     assert call() == 0                                        # the context is still usable after errors
+
+
+def test_f16_prefill_overflow_is_a_loud_error_and_bf16_handles_it(qmm, oracle):
+    """valid GGUF bits the default prefill mode cannot represent: Q4_0 / Q4_K blocks whose d is the largest fp16 (65504; the golden
+    edge row tests/golden/make_golden.py keeps out of the matmul fixtures).  (q - 8) * d overflows the f16 the weights are rounded
+    to: the launch must not return silently wrong numbers: qmm_synchronize reports it, and QMM_PREC_BF16 computes the product
+    (NMSE <= 5e-4, the reference's bar).  The mat-vec path (N <= 8) is exact arithmetic in f32 and is not affected."""
+    import ggml_hexagon_amd.synth as synth
+    from ggml_hexagon_amd.capi import PREC_BF16, PREC_F16_Q8, QmmError
+    k, m, n = 512, 64, 40
+    for t, doff in ((Q4_0, 0), (Q4_K, 0)):
+        w = synth.synth_weights(t, m, k, seed=3, sigma=0.05).reshape(m, -1, synth.TYPE_SIZE[t])
+        w[5, 1, doff:doff + 2] = np.array([0x7BFF], np.uint16).view(np.uint8)         # one block of row 5: d = 65504
+        w = w.reshape(m, -1)
+        x = np.random.default_rng(9).uniform(-1, 1, (n, k)).astype(np.float32)
+        want = oracle.mul_mat(t, w, k, x, ACT_REF)
+        assert np.isfinite(want).all()
+        got1 = qmm.mul_mat(t, dev(w), k, dev(x[:4])).cpu().numpy()                     # mat-vec kernels: fine
+        assert rel_rms(got1, want[:4]) < 2e-5
+        qmm.synchronize()
+        qmm.mul_mat(t, dev(w), k, dev(x))
+        with pytest.raises(QmmError, match="non-finite"):
+            qmm.synchronize()
+        qmm.synchronize()                                                              # the report clears the condition
+        qmm.set_precision(PREC_BF16)
+        got = qmm.mul_mat(t, dev(w), k, dev(x)).cpu().numpy()
+        qmm.synchronize()
+        qmm.set_precision(PREC_F16_Q8)
+        assert nmse(got, want) < 5e-4, (TYPE_NAMES[t], nmse(got, want))
