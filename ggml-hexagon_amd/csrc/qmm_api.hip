@@ -288,6 +288,8 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->act_mode = atoi(e) ? QMM_ACT_X86 : QMM_ACT_REF;
     e = getenv("GGML_MI355X_MV_KMIX");
     if (e) c->mv_kmix = atoi(e);
+    e = getenv("GGML_MI355X_WIDE");
+    if (e) c->wide = atoi(e);
     e = getenv("GGML_MI355X_CHAIN");
     if (e) c->chain_enabled = atoi(e);
     e = getenv("GGML_MI355X_MV_BPC");

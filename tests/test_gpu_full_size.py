@@ -131,3 +131,29 @@ def test_mul_mat_id_at_mixtral_size(qmm, oracle, k, m, n_tokens):
         qmm.mul_mat_id_pair(t, w, w2, k, b, ids_full[:, :n_used], o0, o1)
         assert torch.equal(o0, y) and torch.equal(o1, qmm.mul_mat_id(t, w2, k, b, ids_full[:, :n_used]))
     qmm.synchronize()
+
+
+def test_wide_tiles_equal_the_128_token_kernel(qmm, oracle):
+    """ffn_gate + ffn_up of llama3-8b as ONE launch at 512 tokens takes the 256 x 256 tiles of mfma_regb_q4k_wide_kernel (224 tiles);
+    each matrix alone (112 tiles of 256 x 256 < half the CUs) takes the 256 x 128 kernel.  Both walk K in the same order with the same
+    fragments, so the results must be the same bits; sampled rows against the oracle on top.  ffn_down (K = 14336) takes the wide
+    kernel with K cut 8 ways: against the oracle."""
+    import ggml_hexagon_amd.synth as synth
+    dev = torch.device("cuda", 0)
+    k, m, n = 4096, 14336, 512
+    wg, wu = synth.synth_weights_torch(Q4_K, m, k, dev, seed=1), synth.synth_weights_torch(Q4_K, m, k, dev, seed=2)
+    x = torch.rand((n, k), device=dev, generator=torch.Generator(device=dev).manual_seed(5)) * 2 - 1
+    og, ou = torch.empty((n, m), device=dev), torch.empty((n, m), device=dev)
+    qmm.mul_mat_group([(Q4_K, wg), (Q4_K, wu)], k, x, [og, ou])
+    sg, su = qmm.mul_mat(Q4_K, wg, k, x), qmm.mul_mat(Q4_K, wu, k, x)
+    assert torch.equal(og.view(torch.int32), sg.view(torch.int32)) and torch.equal(ou.view(torch.int32), su.view(torch.int32))
+    rng = np.random.default_rng(3)
+    rows, toks = np.sort(rng.choice(m, 32, replace=False)), np.sort(rng.choice(n, 64, replace=False))
+    want = oracle.mul_mat(Q4_K, wu[torch.from_numpy(rows).to(dev)].cpu().numpy(), k, x.cpu().numpy()[toks], ACT_REF)
+    assert rel_l2(ou.cpu().numpy()[np.ix_(toks, rows)], want) <= 1e-3
+    # ragged token count (not a multiple of 256 after padding to 128): falls back to the 128-token kernel, still correct
+    x2 = x[:300].contiguous()
+    o2 = [torch.empty((300, m), device=dev), torch.empty((300, m), device=dev)]
+    qmm.mul_mat_group([(Q4_K, wg), (Q4_K, wu)], k, x2, o2)
+    assert torch.equal(o2[0], qmm.mul_mat(Q4_K, wg, k, x2))
+    qmm.synchronize()
