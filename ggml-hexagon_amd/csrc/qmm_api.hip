@@ -290,6 +290,8 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->mv_kmix = atoi(e);
     e = getenv("GGML_MI355X_WIDE");
     if (e) c->wide = atoi(e);
+    e = getenv("GGML_MI355X_R64");
+    if (e) c->r64 = atoi(e);
     e = getenv("GGML_MI355X_CHAIN");
     if (e) c->chain_enabled = atoi(e);
     e = getenv("GGML_MI355X_MV_BPC");

@@ -11,5 +11,5 @@ for set in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLE
   rm -rf /tmp/pmc_pass$i
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_pass$i -o t --output-format csv -- python3 $ROOT/profiles/tools/one_shape.py "$@" > /tmp/pmc_pass$i.log 2>&1
   echo "# pass $i: --pmc $set"
-  python3 $ROOT/profiles/tools/pmc_sum.py $(find /tmp/pmc_pass$i -name "*counter_collection.csv" | head -1) mfma_regb
+  python3 $ROOT/profiles/tools/pmc_sum.py $(find /tmp/pmc_pass$i -name "*counter_collection.csv" | head -1) mfma_r
 done

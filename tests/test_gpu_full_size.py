@@ -157,3 +157,61 @@ def test_wide_tiles_equal_the_128_token_kernel(qmm, oracle):
     qmm.mul_mat_group([(Q4_K, wg), (Q4_K, wu)], k, x2, o2)
     assert torch.equal(o2[0], qmm.mul_mat(Q4_K, wg, k, x2))
     qmm.synchronize()
+
+
+@pytest.fixture(scope="module")
+def qmm_by_r64():
+    """contexts with the 64-rows-per-wave Q4_K prefill kernel off (0), in place of the 256 x 128 kernel (bit 0), in place of the
+    256 x 256 one (bit 1) and both (3); the switch is read when a context is created"""
+    import os
+    from ggml_hexagon_amd.capi import Qmm
+    made, old = {}, os.environ.get("GGML_MI355X_R64")
+    try:
+        for v in (0, 1, 2, 3):
+            os.environ["GGML_MI355X_R64"] = str(v)
+            made[v] = Qmm(0)
+    finally:
+        if old is None:
+            os.environ.pop("GGML_MI355X_R64", None)
+        else:
+            os.environ["GGML_MI355X_R64"] = old
+    yield made
+    for q in made.values():
+        q.close()
+
+
+@pytest.mark.parametrize("k,m,n", [(4096, 4096, 512), (4096, 14336, 512), (14336, 4096, 512), (4096, 1000, 300), (8192, 8192, 129),
+                                   (4096, 28672, 512), (4096, 256, 4096)],
+                         ids=["wo-splitk", "gate", "down-splitk", "ragged", "70b-wo", "wide-shape", "few-rows"])
+def test_r64_tiles_equal_the_32_row_kernels(qmm_by_r64, k, m, n):
+    """mfma_r64_q4k_kernel (64 weight rows per wave, activation tile by LDS DMA) walks K in the same order with the same fragments as
+    mfma_regb_q4k_kernel<8,128> and the 256 x 256 kernel: the same bits, whole matrices, with and without split-K, ragged rows/tokens"""
+    import ggml_hexagon_amd.synth as synth
+    dev = torch.device("cuda", 0)
+    w = synth.synth_weights_torch(Q4_K, m, k, dev, seed=k + m)
+    x = torch.rand((n, k), device=dev, generator=torch.Generator(device=dev).manual_seed(n)) * 2 - 1
+    ref = qmm_by_r64[0].mul_mat(Q4_K, w, k, x)
+    for v in (1, 2, 3):
+        got = qmm_by_r64[v].mul_mat(Q4_K, w, k, x)
+        assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (v, k, m, n, float((got - ref).abs().max()))
+    for q in qmm_by_r64.values():
+        q.synchronize()
+
+
+def test_r64_group_launch_equals_the_32_row_kernel(qmm_by_r64):
+    """attn_q / attn_k / attn_v as one launch (RegbMore) with split-K, and ffn_gate + ffn_up as one launch"""
+    import ggml_hexagon_amd.synth as synth
+    dev = torch.device("cuda", 0)
+    k, n = 4096, 512
+    x = torch.rand((n, k), device=dev, generator=torch.Generator(device=dev).manual_seed(9)) * 2 - 1
+    for ms in ((4096, 1024, 1024), (14336, 14336)):
+        ws = [synth.synth_weights_torch(Q4_K, m, k, dev, seed=10 + i) for i, m in enumerate(ms)]
+        outs = {}
+        for v, q in qmm_by_r64.items():
+            o = [torch.empty((n, m), device=dev) for m in ms]
+            q.mul_mat_group([(Q4_K, w) for w in ws], k, x, o)
+            q.synchronize()
+            outs[v] = o
+        for v in (1, 2, 3):
+            for a, b in zip(outs[v], outs[0]):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (v, ms)
