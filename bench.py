@@ -265,7 +265,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_split = world == 1 and os.environ.get("QMM_BENCH_FORCE_SPLIT") == "1"    # rehearsal: a world of one through RCCL and the captured exchange
+    if force_split:
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("MASTER_PORT", "29571")
+    if world > 1 or force_split:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("QMM_BENCH_DIST_BACKEND", "nccl")
@@ -282,7 +285,7 @@ def main():
 
     q = Qmm(local)
     wl = workload.get(args.workload)
-    concat = RowConcat() if world > 1 else None
+    concat = RowConcat(always_collective=force_split) if dist is not None else None
     hp = HotPath(q, wl, dev, rank, world, concat, planar=not args.wire_layout)
     hp.chain = args.chain
     hp.prepare(args.n_prompt)
@@ -291,8 +294,26 @@ def main():
     # n_outputs_all = 1, src/llama-context.cpp:1232-1244): the last layer's FFN and the output projection then run on
     # one row (ggml_get_rows(cur, inp_out_ids), src/llama-model.cpp:4270-4275)
     n_out_pp = None if args.all_logits else 1
-    use_graph = world == 1 and not args.no_graph
-    graph = hp.capture(1) if use_graph else None
+    # token generation replays a hipGraph of the pass.  With a row split the RCCL all-gathers are captured with the launches
+    # (tests/test_gpu_rccl.py rehearses that on one GPU); QMM_BENCH_GRAPH_MULTI=0 keeps N > 1 eager.  A capture that fails on every
+    # rank alike falls back to eager launches instead of ending the run.
+    use_graph = not args.no_graph and (world == 1 or (os.environ.get("QMM_BENCH_GRAPH_MULTI", "1") != "0" and
+                                                     os.environ.get("QMM_BENCH_DIST_BACKEND", "nccl") == "nccl"))   # (gloo stages through the host: not capturable)
+    graph = None
+    if use_graph:
+        try:
+            graph = hp.capture(1)
+        except Exception as e:                       # noqa: BLE001
+            if world == 1:
+                raise
+            print(f"[bench] rank {rank}: hipGraph capture of the split pass failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+        if dist is not None:                         # all ranks take the same path
+            ok = torch.tensor([1 if graph is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                graph = None
 
     def barrier():
         if dist is not None:

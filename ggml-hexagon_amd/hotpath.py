@@ -19,6 +19,7 @@ from .workload import Workload
 class HotPath:
     def __init__(self, qmm, wl: Workload, device, rank: int = 0, world: int = 1, concat=None, seed: int = 1234, planar: bool = True):
         self.q, self.wl, self.dev, self.rank, self.world, self.concat = qmm, wl, device, rank, world, concat
+        self.split = world > 1 or (concat is not None and getattr(concat, "always", False))   # exchange after every group (a forced world of one included)
         self.weights = {}       # name -> (uint8 tensor [rows, row_bytes] | [n_expert, M, row_bytes], ranges)
         self.types = {}         # name -> type code for the C-ABI: the planar code where the rows were re-laid, as the
         #                         plugin does with Q4_0 / Q8_0 / Q6_K weights at their first use; same bytes, same results
@@ -77,8 +78,23 @@ class HotPath:
                     dkey = (m.name.split(".")[-1], rows)
                     if dkey not in dst_local:
                         dst_local[dkey] = torch.empty((n_tokens, rows), device=self.dev)
-                    if self.world > 1 and dkey not in dst_full:
+                    if self.split and dkey not in dst_full:
                         dst_full[dkey] = torch.empty((n_tokens, m.M), device=self.dev)
+        if self.split:
+            # row split: a group's local outputs are column slices of ONE buffer, so that its dst slices travel in one all-gather
+            # (one exchange per group, not per matrix: 129 instead of 225 per token for llama3-8b).  Groups with a ragged split
+            # (rows not a multiple of 64 x world: the output matrix) keep their own buffers and the padded per-matrix exchange.
+            for grp in self.wl.groups:
+                if grp.mats[0].n_expert or len(grp.mats) < 2:
+                    continue
+                rows = [self.weights[m.name][0].shape[0] for m in grp.mats]
+                if any(len({hi - lo for lo, hi in self.weights[m.name][1]}) != 1 for m in grp.mats):
+                    continue
+                gkey = ("group",) + tuple((m.name.split(".")[-1], r) for m, r in zip(grp.mats, rows))
+                if gkey not in dst_local:
+                    buf = torch.empty((n_tokens, sum(rows)), device=self.dev)
+                    offs = [sum(rows[:i]) for i in range(len(rows))]
+                    dst_local[gkey] = (buf, [buf[:, o:o + r] for o, r in zip(offs, rows)])   # the group's launch writes these views
         self.io[n_tokens] = (x, dst_local, dst_full, ids)
         return self.io[n_tokens]
 
@@ -122,13 +138,20 @@ class HotPath:
                 ws.append((self.types[m.name], w))
                 outs.append(dst_local[dkey])
                 keys.append((dkey, ranges))
+            gkey = ("group",) + tuple(dkey for dkey, _ in keys)
+            if self.split and gkey in dst_local:
+                buf, outs = dst_local[gkey]
+                q.mul_mat_group(ws, m0.K, x[m0.K], outs)
+                self.concat.concat_group(buf, [dkey[1] for dkey, _ in keys], [r for _, r in keys], [dst_full[dkey] for dkey, _ in keys])
+                continue
             q.mul_mat_group(ws, m0.K, x[m0.K], outs)
-            if self.world > 1:
+            if self.split:
                 for (dkey, ranges), o in zip(keys, outs):
                     self.concat.concat(o, ranges, out=dst_full[dkey])
 
     def capture(self, n_tokens: int):
-        """hipGraph of one pass (single GPU): removes the per-launch host cost from the token-generation loop"""
+        """hipGraph of one pass: removes the per-launch host cost from the token-generation loop.  With a row split the RCCL
+        all-gathers are captured with the launches (collectives are capturable; tests/test_gpu_rccl.py rehearses it on one GPU)"""
         self.prepare(n_tokens)
         self.run(n_tokens)                  # warm: lazy module loads, workspace growth happen outside the capture
         torch.cuda.synchronize()

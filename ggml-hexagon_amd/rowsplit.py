@@ -33,12 +33,13 @@ class RowConcat:
     Equal slices use one all_gather_into_tensor (RCCL ring/direct over xGMI) into a [world, N, rows] staging
     buffer followed by one permute-copy; ragged slices (last rank takes the remainder) are padded to the widest.  Works unchanged with the gloo backend on CPU tensors (tests)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_collective=False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.always = always_collective      # a world of one still goes through the backend (rehearsal of RCCL + hipGraph capture on a one-GPU box)
         self._stage = {}          # staging buffers by (rows, cols, dtype, device): allocated once, the exchange runs per MUL_MAT group
 
     def _buf(self, rows, cols, like, zero=False):
@@ -57,7 +58,7 @@ class RowConcat:
         sizes = [hi - lo for lo, hi in ranges]
         if out is None:
             out = torch.empty((n, m), dtype=local.dtype, device=local.device)
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             out.copy_(local)
             return out
         equal = len(set(sizes)) == 1 and local.is_contiguous()
@@ -81,3 +82,27 @@ class RowConcat:
                 if hi > lo:
                     out[:, lo:hi] = stage[r, :, :hi - lo]
         return out
+
+    def concat_group(self, local, cols, ranges_list, outs):
+        """ONE all-gather for a group of MUL_MATs that share src1 (attn_q/k/v, ffn_gate/up): `local` is this rank's [N, sum(cols)]
+        buffer whose column slices the group's launch wrote (cols[i] = this rank's rows of matrix i, the same on every rank);
+        outs[i] [N, M_i] receives matrix i's full dst.  The gathered [world, N, sum(cols)] block is taken apart by one strided copy
+        per matrix (the placement the reference's per-device cudaMemcpy2D into the main device's dst does, ggml-cuda.cu:1603-1625)."""
+        n, tot = local.shape
+        assert tot == sum(cols) and local.is_contiguous()
+        if self.world == 1 and not self.always:
+            off = 0
+            for c, o in zip(cols, outs):
+                o.copy_(local[:, off:off + c])
+                off += c
+            return outs
+        stage = self._buf(self.world * n, tot, local)
+        self.dist.all_gather_into_tensor(stage, local, group=self.group)
+        st = stage.view(self.world, n, tot)
+        off = 0
+        for c, ranges, o in zip(cols, ranges_list, outs):
+            assert all(hi - lo == c for lo, hi in ranges), "concat_group needs equal slices (use concat for ragged ones)"
+            o.view(n, self.world, c).copy_(st[:, :, off:off + c].permute(1, 0, 2))
+            off += c
+        return outs
+

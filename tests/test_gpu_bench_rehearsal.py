@@ -27,3 +27,16 @@ def test_bench_two_ranks_on_one_gpu_with_gloo():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 1 and d["value"] > 0
     assert d["config"]["parallelism"].startswith("ggml row split over 2 GPUs") and d["config"]["tg_launch"] == "eager"
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+
+
+def test_bench_split_path_through_rccl_with_a_world_of_one():
+    """the N > 1 code of bench.py on real RCCL: a process group of one rank, the exchange forced through the backend, the
+    token-generation pass with its all-gathers captured in a hipGraph (QMM_BENCH_FORCE_SPLIT=1)"""
+    env = dict(os.environ, QMM_BENCH_FORCE_SPLIT="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--n-gen", "8", "--no-e2e", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout + p.stderr)[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["tg_launch"] == "hipGraph replay", d["config"]
+    assert "capture of the split pass failed" not in p.stderr

@@ -173,20 +173,19 @@ def _hotpath_worker(rank, world, port, q):
                     for t in hp.prepare(n_out)[2].values():      # stale results of the n = 1 pass must not satisfy the check
                         t.zero_()
                 hp.run(n, n_out)
-                if n_out is not None:
-                    n = n_out                                   # the last layer's FFN and the output projection ran at n_outputs
-                x, dst_local, dst_full, _ = hp.prepare(n)
                 # every full dst must equal the single-device product of the concatenated shards
-                for grp in wl.groups[-2:]:                       # last layer's ffn_down + the output projection (ragged split)
+                assert any(isinstance(k, tuple) and k and k[0] == "group" for k in hp.prepare(n)[1]), "grouped exchange not in use"
+                for grp in wl.groups[-5:]:                       # the last layer (q/k/v and gate/up travel as ONE all-gather each) + the output projection (ragged split)
+                    nn = n_out if (n_out is not None and grp.outputs_only) else n     # the last layer's FFN and the output projection ran at n_outputs
+                    x, dst_local, dst_full, _ = hp.prepare(nn)
                     for m in grp.mats:
                         w_local, ranges = hp.weights[m.name]
-                        parts = [torch.zeros(0)] * world
                         gathered = [None] * world
                         dist.all_gather_object(gathered, w_local.numpy())
                         w_full = np.concatenate([g for g in gathered if g.shape[0] > 0])
                         want = qm.o.mul_mat(m.type, w_full, m.K, x[m.K].numpy())
                         got = dst_full[(m.name.split(".")[-1], w_local.shape[0])].numpy()
-                        assert got.shape == want.shape and np.array_equal(got, want), m.name
+                        assert got.shape == want.shape and np.array_equal(got, want), (m.name, n, n_out)
             q.put((rank, True))
         finally:
             synth.synth_weights_torch = orig
