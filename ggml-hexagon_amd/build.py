@@ -24,9 +24,9 @@ def _newer(target: Path, sources) -> bool:
 
 def build_qmm(force: bool = False) -> Path:
     """the kernel library behind include/ggml_mi355x_qmm.h and include/ggml_mi355x_ops.h: one object per translation unit
-    (qmm_api.hip = the quantized MUL_MAT path, qmm_ops.hip = the glue ops), rebuilt only when its sources changed"""
+    (qmm_api.hip = the quantized MUL_MAT path, qmm_ops.hip = the glue ops, qmm_comm.hip = the RCCL exchange of a one-process row split), rebuilt only when its sources changed"""
     headers = sorted(CSRC.glob("qmm_*.hiph")) + sorted(CSRC.glob("qmm_*.h")) + sorted((ROOT / "include").glob("ggml_mi355x_*.h"))
-    units = [CSRC / "qmm_api.hip", CSRC / "qmm_ops.hip"]
+    units = [CSRC / "qmm_api.hip", CSRC / "qmm_ops.hip", CSRC / "qmm_comm.hip"]
     if not force and _newer(QMM_SO, units + headers):
         return QMM_SO
     if not shutil.which(HIPCC):
@@ -42,7 +42,7 @@ def build_qmm(force: bool = False) -> Path:
     for j in jobs:
         if j.wait() != 0:
             raise subprocess.CalledProcessError(j.returncode, j.args)
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(QMM_SO), *map(str, objs)], check=True)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(QMM_SO), *map(str, objs), "-ldl"], check=True)
     return QMM_SO
 
 

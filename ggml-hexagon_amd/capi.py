@@ -21,6 +21,7 @@ EXPORTS = [
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_planar_type", "qmm_repack_rows", "qmm_dequantize",
     "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_swiglu_in", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
     "qmm_chain_begin", "qmm_chain_flush", "qmm_chain_end", "qmm_chain_stats", "qmm_chain_debug",
+    "qmm_comm_create", "qmm_comm_destroy", "qmm_comm_size", "qmm_comm_broadcast", "qmm_comm_gather", "qmm_comm_all_gather",
 ]
 # include/ggml_mi355x_ops.h: the glue ops of a transformer layer
 OPS_EXPORTS = [

@@ -315,7 +315,7 @@ ggml_backend_buffer_type_t host_buffer_type() {
 // owns one allocation per (tensor, device); tensor->data is a dummy and tensor->extra points at the slices.
 // Only whole-tensor set_tensor / get_tensor, as in the reference (:800-885).
 
-constexpr int64_t SPLIT_ROW_ROUNDING = 64;
+constexpr int64_t SPLIT_ROW_ROUNDING = 256;    // the prefill kernels' row tile (every device's slice starts on a tile; round 1 used 64: ragged tiles on every device)
 
 struct split_buft_ctx {
     int         main_device;
@@ -490,12 +490,90 @@ bool grow(mi355x_device_ctx * d, void *& p, size_t & have, size_t need) {
 // fabric, computes its rows into a staging slice and copies that into the root's dst (N runs of `rows` floats).  All of it
 // is stream-ordered: devices wait for the root's "src1 ready" event, the root waits for each device's "slice landed".
 // The exchange is a concat, so there is no reduction and the result does not depend on the number of devices.
+// GGML_MI355X_RCCL=1: the same exchange through RCCL (qmm_comm_*: ncclBroadcast of src1, grouped ncclSend / ncclRecv of the slices)
+// instead of peer copies + events.  One communicator over all devices of the process, made at the first split MUL_MAT; where RCCL
+// cannot serve (a library that is not there, logical devices that share a GPU) the peer-copy path stays, with one log line.
+qmm_comm * g_comm = nullptr;
+int        g_comm_state = 0;      // 0 = not tried, 1 = in use, -1 = unavailable
+qmm_comm * split_comm() {
+    if (g_comm_state == 0) {
+        const char * e = getenv("GGML_MI355X_RCCL");
+        g_comm_state = -1;
+        if (e && atoi(e) && g_ndev >= 2) {
+            std::vector<qmm_ctx *> cs;
+            for (int i = 0; i < g_ndev; ++i) cs.push_back(g_devs[i].qmm);
+            if (qmm_comm_create(cs.data(), g_ndev, &g_comm) == 0) g_comm_state = 1;
+            else GGML_LOG_WARN("MI355X row split: RCCL exchange unavailable (%s); using peer copies\n", qmm_last_error());
+        }
+    }
+    return g_comm_state == 1 ? g_comm : nullptr;
+}
+
+enum ggml_status compute_mul_mat_split_rccl(mi355x_backend_ctx * ctx, const ggml_tensor * dst, qmm_comm * comm) {
+    const ggml_tensor * a = dst->src[0], * b = dst->src[1];
+    auto * e = (const split_extra *) a->extra;
+    mi355x_device_ctx * root = ctx->dev;
+    const int root_id = (int) (root - &g_devs[0]);
+    const int64_t K = a->ne[0], N = b->ne[1], ldd = dst->nb[1] / sizeof(float);
+    std::vector<void *> xs(g_ndev), recv(g_ndev, nullptr);
+    std::vector<const void *> send(g_ndev, nullptr);
+    std::vector<size_t> bytes(g_ndev, 0);
+    // the root receives the slices into a staging block (N x rows per device, back to back) unless N == 1, where a slice IS a run of dst
+    size_t stage_total = 0;
+    for (int id = 0; id < g_ndev; ++id)
+        if (id != root_id) stage_total += (size_t) N * (e->hi[id] - e->lo[id]) * sizeof(float);
+    if (N > 1 && !grow(root, root->stage_d, root->stage_d_bytes, stage_total)) goto fail;
+    {
+        size_t off = 0;
+        for (int id = 0; id < g_ndev; ++id) {
+            mi355x_device_ctx * d = &g_devs[id];
+            const int64_t rows = e->hi[id] - e->lo[id];
+            if (id == root_id) { xs[id] = b->data; continue; }
+            if (!grow(d, d->stage_x, d->stage_x_bytes, (size_t) N * K * sizeof(float)) ||
+                !grow(d, d->stage_d, d->stage_d_bytes, (size_t) N * rows * sizeof(float))) goto fail;
+            xs[id] = d->stage_x;
+            send[id] = d->stage_d;
+            bytes[id] = (size_t) N * rows * sizeof(float);
+            recv[id] = N == 1 ? (void *) ((float *) dst->data + e->lo[id]) : (void *) ((char *) root->stage_d + off);
+            off += bytes[id];
+        }
+        if (qmm_comm_broadcast(comm, root_id, xs.data(), (size_t) N * K * sizeof(float), nullptr)) goto fail;
+        for (int id = 0; id < g_ndev; ++id) {
+            mi355x_device_ctx * d = &g_devs[id];
+            const int64_t rows = e->hi[id] - e->lo[id];
+            if (rows == 0) continue;
+            if (id == root_id) {
+                if (qmm_mul_mat(d->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) b->data, N, K,
+                                (float *) dst->data + e->lo[id], ldd, qmm_stream(d->qmm))) goto fail;
+            } else if (qmm_mul_mat(d->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) d->stage_x, N, K,
+                                   (float *) d->stage_d, rows, qmm_stream(d->qmm))) goto fail;
+        }
+        if (qmm_comm_gather(comm, root_id, send.data(), recv.data(), bytes.data(), nullptr)) goto fail;
+        if (N > 1) {                                           // place the slices: N runs of `rows` floats each
+            off = 0;
+            for (int id = 0; id < g_ndev; ++id) {
+                const int64_t rows = e->hi[id] - e->lo[id];
+                if (id == root_id || rows == 0) continue;
+                if (qmm_memcpy2d_d2d(root->qmm, (float *) dst->data + e->lo[id], dst->nb[1], (char *) root->stage_d + off,
+                                     rows * sizeof(float), rows * sizeof(float), N, qmm_stream(root->qmm))) goto fail;
+                off += bytes[id];
+            }
+        }
+    }
+    return GGML_STATUS_SUCCESS;
+fail:
+    GGML_LOG_ERROR("MI355X MUL_MAT(%s) row split over RCCL: %s\n", dst->name, qmm_last_error());
+    return GGML_STATUS_FAILED;
+}
+
 enum ggml_status compute_mul_mat_split(mi355x_backend_ctx * ctx, const ggml_tensor * dst) {
     const ggml_tensor * a = dst->src[0], * b = dst->src[1];
     auto * e = (const split_extra *) a->extra;
     mi355x_device_ctx * root = ctx->dev;
     void * rst = qmm_stream(root->qmm);
     const int64_t K = a->ne[0], N = b->ne[1], ldx = b->nb[1] / sizeof(float), ldd = dst->nb[1] / sizeof(float);
+    if (ldx == K)                                             // (RCCL moves whole buffers: a strided src1 keeps the 2-D peer copies)
+        if (qmm_comm * comm = split_comm()) return compute_mul_mat_split_rccl(ctx, dst, comm);
     if (!root->ev_ready) root->ev_ready = qmm_event_create(root->qmm);
     if (!root->ev_ready || qmm_event_record(root->qmm, root->ev_ready, rst)) goto fail;
     for (int id = 0; id < g_ndev; ++id) {

@@ -225,6 +225,26 @@ QMM_API int qmm_mul_mat_id_pair(qmm_ctx * ctx, int type, const void * as0, const
                                 const int32_t * ids, int64_t n_used, int64_t n_tokens, int64_t ids_nb1,
                                 float * dst0, float * dst1, int64_t d_nb1, int64_t d_nb2, void * stream);
 
+/* ---- RCCL exchange for a row split driven from ONE process ----------------------------------------------------------
+ * Replaces: the reference's only row-split data path, ggml_cuda_op_mul_mat's cudaMemcpyPeerAsync of src1 to every device and of the
+ * dst slices back to the main device (ggml/src/ggml-cuda/ggml-cuda.cu:1365-1673; placement of the slices :1603-1625).  Rank r of a
+ * communicator is ctxs[r]; one rank per device (RCCL's rule).  Every call is enqueued on the ranks' streams (streams[r], or the
+ * context's own stream when `streams` is NULL) and returns at once.  librccl.so is opened on the first qmm_comm_create;
+ * QMM_EUNSUPPORTED when it cannot be found (GGML_MI355X_RCCL_LIB names another path).
+ * The plugin uses it for split MUL_MATs with GGML_MI355X_RCCL=1 (default: peer copies + events, which need no library);
+ * one-process-per-GPU callers exchange through torch.distributed's RCCL instead (ggml-hexagon_amd/rowsplit.py). */
+typedef struct qmm_comm qmm_comm;
+QMM_API int  qmm_comm_create(qmm_ctx * const * ctxs, int n, qmm_comm ** out);
+QMM_API void qmm_comm_destroy(qmm_comm * comm);
+QMM_API int  qmm_comm_size(const qmm_comm * comm);
+/* bufs[root] (on rank root) -> bufs[r] on every rank, `bytes` each: src1 of a split MUL_MAT */
+QMM_API int  qmm_comm_broadcast(qmm_comm * comm, int root, void * const * bufs, size_t bytes, void * const * streams);
+/* send[r] (bytes[r] on rank r) -> recv[r] on the root, for every r != root with bytes[r] > 0: the dst slices, one grouped launch */
+QMM_API int  qmm_comm_gather(qmm_comm * comm, int root, const void * const * send, void * const * recv, const size_t * bytes,
+                             void * const * streams);
+/* send[r] (`bytes` on rank r) -> recv[r] (size * bytes on every rank, in rank order) */
+QMM_API int  qmm_comm_all_gather(qmm_comm * comm, const void * const * send, void * const * recv, size_t bytes, void * const * streams);
+
 #ifdef __cplusplus
 }
 #endif
