@@ -624,11 +624,26 @@ bool bytes_overlap(const void * a, size_t an, const void * b, size_t bn) {
 // block that was freed once the earlier nodes' operands were dead, i.e. exactly the memory the launch still reads: other workgroups
 // would overwrite it while it is being staged.  Legal only when `late` is disjoint from every operand (an operand at the very same
 // address with the same row layout is fine where the launch reads an element before the same thread writes it: `inplace_ok`).
-bool early_write_ok(const ggml_tensor * late, std::initializer_list<const ggml_tensor *> operands, const ggml_tensor * inplace_ok = nullptr) {
+// The attention launches (qmm_attn_decode*, qmm_attn_prefill) write ct = the merged heads [Dv * H, N]; ggml-alloc likes to give ct
+// the block of the dead Q.  That is in place and safe when the two coincide head for head: a workgroup owns one (head, token), reads
+// its whole q row before anything else and writes the same bytes last; nobody else touches them.  `qv` is a view of Q as [D, H, N]
+// (reshaped) or [D, N, H] (permuted); D must equal Dv.
+bool attn_q_coincides(const ggml_tensor * ct, const ggml_tensor * qv) {
+    if (!qv || qv->data != ct->data || qv->type != GGML_TYPE_F32 || qv->nb[0] != 4 || qv->ne[3] != 1) return false;
+    const int64_t D = qv->ne[0];
+    int hd = 1, td = 2;                                                             // head / token dimension of the view
+    if (qv->nb[1] != (size_t) D * 4) { hd = 2; td = 1; }
+    return qv->nb[hd] == (size_t) D * 4 && qv->nb[td] == ct->nb[1] && D * qv->ne[hd] == ct->ne[0] && qv->ne[td] == ct->ne[1];
+}
+bool early_write_ok(const ggml_tensor * late, std::initializer_list<const ggml_tensor *> operands, const ggml_tensor * inplace_ok = nullptr,
+                    bool attn_q = false) {
     for (const ggml_tensor * o : operands) {
         if (!o || !ranges_overlap(late, o)) continue;
         if (o == inplace_ok && o->data == late->data && o->nb[1] == late->nb[1] && ggml_are_same_shape(o, late)) continue;
-        if (dbg()) fprintf(stderr, "fusion declined: %s would be written early over %s\n", late->name, o->name);
+        if (attn_q && o == inplace_ok && attn_q_coincides(late, o)) continue;
+        if (dbg()) fprintf(stderr, "fusion declined: %s would be written early over %s (%p ne %lld,%lld nb1 %zu | %p ne %lld,%lld,%lld nb %zu,%zu,%zu)\n", late->name, o->name,
+                           late->data, (long long) late->ne[0], (long long) late->ne[1], late->nb[1], o->data, (long long) o->ne[0], (long long) o->ne[1],
+                           (long long) o->ne[2], o->nb[0], o->nb[1], o->nb[2]);
         return false;
     }
     return true;
@@ -673,6 +688,7 @@ void * hoist_elsewhere(mi355x_backend_ctx * ctx, const ggml_tensor * d) {
     auto pos = ctx->redirects.begin();
     while (pos != ctx->redirects.end() && pos->last_reader <= it->last_reader) ++pos;
     ctx->redirects.insert(pos, { d, p, it->last_reader });
+    if (dbg()) fprintf(stderr, "redirect %s (%p) -> scratch %p, readers %d, last reader node %d\n", d->name, d->data, (void *) p, it->uses, it->last_reader);
     return p;
 }
 
@@ -714,8 +730,8 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
             }
             skipped.push_back(d);
         }
-        if (dbg()) fprintf(stderr, "group of %d at %s (N=%lld)\n", n, dst->name, (long long) N);
-        const float * x = (const float *) b->data;
+        if (dbg()) fprintf(stderr, "group of %d at %s (N=%lld) src1 %s %p -> %p\n", n, dst->name, (long long) N, b->name, b->data, to_qt(b, ctx).data);
+        const float * x = (const float *) to_qt(b, ctx).data;                  // (a merged-heads CONT may live in the scratch: attention sites)
         int64_t ldx = b->nb[1] / sizeof(float);
         qmm_mv_extra ex{};
         bool use_ex = false;
@@ -1070,7 +1086,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
             const ggml_tensor * n0 = cgraph->nodes[i];
             if (n0->op == GGML_OP_RMS_NORM || (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU) ||
                 n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT || n0->op == GGML_OP_ROPE || n0->op == GGML_OP_MUL ||
-                n0->op == GGML_OP_GET_ROWS || n0->op == GGML_OP_SUM_ROWS || n0->op == GGML_OP_ADD)
+                n0->op == GGML_OP_GET_ROWS || n0->op == GGML_OP_SUM_ROWS || n0->op == GGML_OP_ADD || n0->op == GGML_OP_CONT)
                 rd.push_back({ n0, 0, -1, true });
         }
         if (!rd.empty()) {
@@ -1080,13 +1096,16 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                 const ggml_tensor * n = cgraph->nodes[i];
                 if (is_noop(n)) continue;                                          // a view reads nothing; its readers are found through view_src
                 const bool glue = glue_op(n) != 0;
+                // a quantized 2-D MUL_MAT of this device takes its src1 pointer through to_qt as well (compute_mul_mat)
+                const bool mm_src1 = !glue && n->op == GGML_OP_MUL_MAT && n->src[0] && n->src[1] && !is_split(n->src[0]) && n->src[0]->ne[2] == 1 &&
+                                     n->src[0]->ne[3] == 1 && n->src[1]->ne[2] == 1 && n->src[1]->ne[3] == 1;
                 for (int j = 0; j < GGML_MAX_SRC && n->src[j]; ++j) {
                     const ggml_tensor * root = n->src[j]->view_src ? n->src[j]->view_src : n->src[j];
                     auto it = std::lower_bound(rd.begin(), rd.end(), root, less);
                     if (it != rd.end() && it->t == root) {
                         ++it->uses;
                         it->last_reader = i;
-                        it->glue_only = it->glue_only && glue;
+                        it->glue_only = it->glue_only && (glue || (mm_src1 && j == 1 && it->t->op == GGML_OP_CONT));   // (only the merged-heads CONT is sent to the scratch on this account)
                     }
                 }
             }
@@ -1208,7 +1227,8 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                         kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm && kqv->src[0]->type == GGML_TYPE_F16 && single_use(kqv) &&
                         pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv && pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] &&
                         pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm &&
-                        early_write_ok(ct, { node->src[1], node->src[0], kqv->src[0], sm->src[1] })) {
+                        ((early_write_ok(ct, { node->src[0], kqv->src[0], sm->src[1] }) && early_write_ok(ct, { node->src[1] }, node->src[1], true)) ||
+                         hoist_elsewhere(ctx, ct))) {      // ggml-alloc puts ct across the dead Q blocks in llama.cpp's layers: written to the scratch instead, wo reads it there
                         const qmm_tensor q = to_qt(node->src[1], ctx), kk = to_qt(node->src[0], ctx), v = to_qt(kqv->src[0], ctx), m = to_qt(sm->src[1], ctx), d = to_qt(ct, ctx);
                         const bool few = qmm_attn_decode_supported(&q, &kk, &v, &m, &d) != 0;
                         if (few || qmm_attn_prefill_supported(&q, &kk, &v, &m, &d)) {
@@ -1237,7 +1257,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                         ct->type == GGML_TYPE_F32 && ggml_is_contiguous(ct) && ggml_nelements(ct) == ggml_nelements(node) &&
                         early_write_ok(ct, { node->src[0], node->src[1] })) {
                         qmm_tensor d = to_qt(node, ctx);
-                        d.data = ct->data;                                            // element (d, n, h) of kqv = element (d, h, n) of the merged result
+                        d.data = to_qt(ct, ctx).data;                                 // element (d, n, h) of kqv = element (d, h, n) of the merged result (ct may live in the scratch)
                         d.nb[1] = (int64_t) node->ne[0] * node->ne[2] * 4;
                         d.nb[2] = (int64_t) node->ne[0] * 4;
                         d.nb[3] = (int64_t) ggml_nbytes(ct);
@@ -1392,8 +1412,10 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                                 max_bias == 0.0f && single_use(sm) && kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm &&
                                 kqv->src[0]->type == GGML_TYPE_F16 && single_use(kqv) && pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv &&
                                 pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] && pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm &&
-                                early_write_ok(ct, { node->src[0], node->src[1], node->src[2], node, cgraph->nodes[jk]->src[0], cgraph->nodes[jcv]->src[0],
-                                                     kqn->src[0], kqv->src[0], sm->src[1] })) {
+                                ((early_write_ok(ct, { node->src[1], node->src[2], cgraph->nodes[jk]->src[0], cgraph->nodes[jcv]->src[0],
+                                                       kqn->src[0], kqv->src[0], sm->src[1] }) &&
+                                  early_write_ok(ct, { node->src[0] }, node->src[0], true) && early_write_ok(ct, { node }, node, true)) ||
+                                 hoist_elsewhere(ctx, ct))) {
                                 const qmm_tensor kc = to_qt(kqn->src[0], ctx), vc = to_qt(kqv->src[0], ctx), m = to_qt(sm->src[1], ctx), d = to_qt(ct, ctx);
                                 const int64_t off = (const char *) kd.data - (const char *) kc.data;
                                 const int64_t j0 = kc.nb[1] > 0 && off >= 0 && off % kc.nb[1] == 0 ? off / kc.nb[1] : -1;

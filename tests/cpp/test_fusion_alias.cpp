@@ -140,6 +140,27 @@ int main() {
             G.fresh(f1); G.fresh(f2);
             G.outs = { f1, f2 };
         });
+        // 5./6. build_attn_mha's chain (kq -> soft_max -> kqv -> permute -> cont) as ONE launch with the merged-heads CONT on the dead Q:
+        // exactly on it (llama.cpp's graphs get this placement from ggml-alloc in every layer; head for head in place, the fused
+        // launch may keep it) and one head further (must be declined or survived)
+        for (int shift = 0; shift < 2; ++shift)
+            compare(shift ? "merged heads placed on Q, one head further" : "merged heads placed exactly on Q", N, gpu, cpu, [&](Graph & G, std::mt19937 & rng) {
+                const int64_t D = 128, H = 8, Hk = 2, n_kv = 256;
+                ggml_tensor * qf = weight(G, rng, GGML_TYPE_F32, D * H, N + 1, 1.0f);                     // one spare row behind Q
+                ggml_tensor * kc = weight(G, rng, GGML_TYPE_F16, D, n_kv * Hk, 1.0f), * vc = weight(G, rng, GGML_TYPE_F16, n_kv, D * Hk, 1.0f);
+                ggml_tensor * mk = weight(G, rng, GGML_TYPE_F32, n_kv, N, 1.0f);
+                ggml_tensor * q3 = ggml_view_3d(G.ctx, qf, D, H, N, D * 4, D * H * 4, 0);
+                ggml_tensor * qp = ggml_permute(G.ctx, q3, 0, 2, 1, 3);
+                ggml_tensor * k3 = ggml_view_3d(G.ctx, kc, D, n_kv, Hk, D * 2, D * n_kv * 2, 0);
+                ggml_tensor * v3 = ggml_view_3d(G.ctx, vc, n_kv, D, Hk, n_kv * 2, n_kv * D * 2, 0);
+                ggml_tensor * kq = ggml_mul_mat(G.ctx, k3, qp);                                           G.fresh(kq);
+                ggml_tensor * sm = ggml_soft_max_ext(G.ctx, kq, mk, 0.0883883f, 0.0f);                    G.fresh(sm);
+                ggml_tensor * kqv = ggml_mul_mat(G.ctx, v3, sm);                                          G.fresh(kqv);
+                ggml_tensor * pm = ggml_permute(G.ctx, kqv, 0, 2, 1, 3);
+                ggml_tensor * ct = ggml_cont_2d(G.ctx, pm, D * H, N);          G.at(ct, G.place[0].off + (shift ? D * 4 : 0));   // on Q
+                ggml_tensor * fin = ggml_scale(G.ctx, ct, 1.0f);               G.fresh(fin);
+                G.outs = { fin };
+            });
     }
     ggml_backend_free(gpu);
     ggml_backend_free(cpu);
