@@ -851,6 +851,70 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
             }
         }
     }
+    if (g.n_kv <= 512) {
+        // Short caches (token generation from an empty context: n_kv = 256): the kernel is a chain of latencies, not of bytes (12.9 us
+        // per layer for 64 KB of K and V), so the softmax is done by EVERY wave for itself from the scores in LDS: one barrier instead
+        // of seven, no block reductions, and the wave's eight V rows are requested together instead of in two trips.  A lane owns the
+        // eight columns it multiplies (j = 8 lane ...).  Same max, same exponentials; the sum runs in another order than below.
+        __syncthreads();                                // sc[] complete
+        const int lane = tid & 63, wave = tid >> 6;
+        const int jl = lane * 8;
+        const bool live = jl < g.n_kv;                  // (n_kv is a multiple of 8: qmm_attn_decode_supported)
+        const int jc = live ? jl : 0;
+        const char * pv = g.v + (int64_t) hk * g.v_nb2;
+        float * out = (float *) (g.dst + (int64_t) n * g.d_nb1) + (int64_t) h * g.Dv;
+        h16x8 vv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {                   // rows wave + 16 r of the first 128; requested before the softmax arithmetic
+            const int d = wave + 16 * r < g.Dv ? wave + 16 * r : wave;
+            vv[r] = *(const h16x8 *) (pv + (int64_t) d * g.v_nb1 + (int64_t) jc * 2);
+        }
+        float sv[8], m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sv[e] = live ? sc[jl + e] : -INFINITY; m = fmaxf(m, sv[e]); }
+        m = wave_max(m);
+        float sum = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sv[e] = live ? expf(sv[e] - m) : 0.0f; sum += sv[e]; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        float pr[8], pfresh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pr[e] = (float) (_Float16) (sv[e] * inv);
+        if (FRESH) {                                    // the batch's own positions: probability set aside, column weight 0 (see below)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pfresh[i] = i < f.N ? (float) (_Float16) (expf(sc[f.j0 + i] - m) * inv) : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (i < f.N && jl + e == f.j0 + i) pr[e] = 0.0f;
+            }
+        }
+        for (int d0 = wave; d0 < g.Dv; d0 += 128) {
+            if (d0 != wave) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int d = d0 + 16 * r < g.Dv ? d0 + 16 * r : d0;
+                    vv[r] = *(const h16x8 *) (pv + (int64_t) d * g.v_nb1 + (int64_t) jc * 2);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += (float) vv[r][e] * pr[e];
+                float t = wave_sum(acc);
+                const int d = d0 + 16 * r;
+                if (lane == 0 && d < g.Dv) {
+                    if (FRESH) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) if (i < f.N) t += pfresh[i] * (float) vnew[i * g.Dv + d];
+                    }
+                    out[d] = t;
+                }
+            }
+        }
+        return;
+    }
     mx = block_reduce<true>(mx, red);                   // its barriers also publish sc[]
     float sum = 0.0f;
     for (int j = tid; j < g.n_kv; j += 1024) {
