@@ -194,3 +194,25 @@ def test_graph_capture_of_a_chain(qmm):
         torch.cuda.synchronize()
         for k, v in L.bufs.items():
             assert torch.equal(v.view(torch.int32), want[k].view(torch.int32)), k
+
+
+@pytest.mark.parametrize("t", [Q4_K, Q8_0, Q6_K], ids=["q4_K", "q8_0", "q6_K"])
+def test_fused_norm_does_not_depend_on_the_launch_geometry(qmm, t):
+    """the RMS_NORM folded into a mat-vec launch sums its squares in a fixed order (1024 virtual threads, stage_rms_norm): the same rows
+    through a 16-wave, an 8-wave and a 4-wave launch (4096, 2048 and 512 rows on 256 CUs) give the same bits.  Until round 2 the
+    partition followed blockDim, and about one input in 150 quantized one activation differently between an 8-wave launch and the
+    16-wave chain kernel."""
+    d = 4096
+    w = W(t, d, d, 3)
+    nw = torch.rand(d, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) + 0.5
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for _ in range(40):
+        x = torch.rand((1, d), device="cuda", generator=g) * 2 - 1
+        outs = []
+        for rows in (4096, 2048, 512):
+            o = torch.empty((1, rows), device="cuda")
+            qmm.mul_mat_group_ex([(t, w[:rows])], d, x, [o], norm_w=nw, eps=1e-5)
+            outs.append(o)
+        qmm.synchronize()
+        assert torch.equal(outs[0][:, :2048].view(torch.int32), outs[1].view(torch.int32))
+        assert torch.equal(outs[0][:, :512].view(torch.int32), outs[2].view(torch.int32))
