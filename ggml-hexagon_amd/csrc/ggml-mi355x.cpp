@@ -1086,7 +1086,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
             const ggml_tensor * n0 = cgraph->nodes[i];
             if (n0->op == GGML_OP_RMS_NORM || (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU) ||
                 n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT || n0->op == GGML_OP_ROPE || n0->op == GGML_OP_MUL ||
-                n0->op == GGML_OP_GET_ROWS || n0->op == GGML_OP_SUM_ROWS || n0->op == GGML_OP_ADD || n0->op == GGML_OP_CONT)
+                n0->op == GGML_OP_GET_ROWS || n0->op == GGML_OP_SUM_ROWS || n0->op == GGML_OP_ADD || n0->op == GGML_OP_CONT || n0->op == GGML_OP_DIV)
                 rd.push_back({ n0, 0, -1, true });
         }
         if (!rd.empty()) {
@@ -1314,15 +1314,32 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                 float scale, max_bias;
                 memcpy(&scale, (const float *) node->op_params + 0, sizeof(float));
                 memcpy(&max_bias, (const float *) node->op_params + 1, sizeof(float));
-                int idx[4], k = 0;
-                for (int j = i + 1; j < n_nodes && j <= i + 2 * LOOKAHEAD && k < 4; ++j) {
-                    if (done[j] || is_noop(cgraph->nodes[j])) continue;
-                    idx[k++] = j;
-                }
+                // llama.cpp's graph order puts get_rows / sum_rows / div (the weights, needed only by the final mul) BEHIND the expert
+                // MUL_MAT_IDs: the argsort follows the soft_max directly, the other three are looked for further down and run here,
+                // early (their inputs exist; where the div's buffer is still in use at this point the weights go to the scratch)
                 const auto root = [](const ggml_tensor * t) { return t->view_src ? t->view_src : t; };
+                int idx[4], k = 0;
+                std::vector<const ggml_tensor *> & skipped = ctx->skipped;
+                skipped.clear();
+                for (int j = i + 1; j < n_nodes && j <= i + 64 && k < 4; ++j) {
+                    const ggml_tensor * t = cgraph->nodes[j];
+                    if (done[j] || is_noop(t)) continue;
+                    const bool want = (k == 0 && t->op == GGML_OP_ARGSORT && t->src[0] == node) ||
+                                      (k == 1 && t->op == GGML_OP_GET_ROWS && root(t->src[0]) == node && root(t->src[1]) == cgraph->nodes[idx[0]]) ||
+                                      (k == 2 && t->op == GGML_OP_SUM_ROWS && root(t->src[0]) == cgraph->nodes[idx[1]]) ||
+                                      (k == 3 && t->op == GGML_OP_DIV && root(t->src[0]) == cgraph->nodes[idx[1]] && t->src[1] == cgraph->nodes[idx[2]]);
+                    if (want) idx[k++] = j;
+                    else if (k == 0) break;                                             // the argsort must come first
+                    else skipped.push_back(t);
+                }
                 if (k == 4 && scale == 1.0f && max_bias == 0.0f) {
                     ggml_tensor * as = cgraph->nodes[idx[0]], * gr = cgraph->nodes[idx[1]], * sr = cgraph->nodes[idx[2]], * dv = cgraph->nodes[idx[3]];
                     const auto * ri = info(node), * rg = info(gr), * rs = info(sr);
+                    if (dbg() && as->op == GGML_OP_ARGSORT)
+                        fprintf(stderr, "router at %s: next %s %s %s %s | uses probs %d rows %d sum %d | contiguous dv %d gr %d | ids view %d\n", node->name, ggml_op_name(as->op),
+                                ggml_op_name(gr->op), ggml_op_name(sr->op), ggml_op_name(dv->op), ri ? ri->uses : -1, rg ? rg->uses : -1, rs ? rs->uses : -1,
+                                (int) ggml_is_contiguous(dv), (int) ggml_is_contiguous(gr),
+                                (int) (gr->op == GGML_OP_GET_ROWS && gr->src[1]->data == as->data && gr->src[1]->nb[1] == as->nb[1] && gr->src[1]->ne[1] == as->ne[1]));
                     if (as->op == GGML_OP_ARGSORT && as->src[0] == node && as->op_params[0] == GGML_SORT_ORDER_DESC &&
                         gr->op == GGML_OP_GET_ROWS && root(gr->src[0]) == node && gr->src[0]->ne[0] == 1 && root(gr->src[1]) == as &&
                         gr->src[1]->data == as->data && gr->src[1]->nb[1] == as->nb[1] && gr->src[1]->ne[1] == as->ne[1] &&
@@ -1330,6 +1347,8 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                         ri && ri->uses == 2 && rg && rg->uses == 2 && rs && rs->uses == 1 && ggml_is_contiguous(dv) && ggml_is_contiguous(gr) &&
                         !(node->flags & GGML_TENSOR_FLAG_OUTPUT) && !(gr->flags & GGML_TENSOR_FLAG_OUTPUT) && !(sr->flags & GGML_TENSOR_FLAG_OUTPUT)) {
                         const int64_t n_used = gr->src[1]->ne[0];
+                        // the weights are written now, not at the div's place in the graph: its block must be free here
+                        if (!can_hoist(dv, skipped) && !hoist_elsewhere(ctx, dv)) goto router_done;
                         const qmm_tensor lg = to_qt(node->src[0], ctx), ids = to_qt(as, ctx), w = to_qt(dv, ctx);
                         if (qmm_moe_router_supported(&lg, &ids, &w, n_used)) {
                             if (qmm_moe_router(ctx->dev->qmm, &lg, &ids, &w, n_used, 1, qmm_stream(ctx->dev->qmm))) {
@@ -1341,6 +1360,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                         }
                     }
                 }
+                router_done:;
             }
             if (node->op == GGML_OP_ROPE && !GGML_MI355X_FUSE_OFF()) {
                 // rope(q) with, from further down the graph, rope(k) -> K cache and v -> V cache (build_attn's two ggml_cpy): one launch
