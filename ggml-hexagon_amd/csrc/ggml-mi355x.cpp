@@ -1237,6 +1237,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                                 GGML_LOG_ERROR("MI355X attention(%s): %s\n", node->name, qmm_last_error());
                                 return GGML_STATUS_FAILED;
                             }
+                            if (dbg()) fprintf(stderr, "fused: attention (%s, %s)\n", few ? "few tokens" : "prompt", node->name);
                             for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
                             continue;
                         }
@@ -1335,11 +1336,6 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                 if (k == 4 && scale == 1.0f && max_bias == 0.0f) {
                     ggml_tensor * as = cgraph->nodes[idx[0]], * gr = cgraph->nodes[idx[1]], * sr = cgraph->nodes[idx[2]], * dv = cgraph->nodes[idx[3]];
                     const auto * ri = info(node), * rg = info(gr), * rs = info(sr);
-                    if (dbg() && as->op == GGML_OP_ARGSORT)
-                        fprintf(stderr, "router at %s: next %s %s %s %s | uses probs %d rows %d sum %d | contiguous dv %d gr %d | ids view %d\n", node->name, ggml_op_name(as->op),
-                                ggml_op_name(gr->op), ggml_op_name(sr->op), ggml_op_name(dv->op), ri ? ri->uses : -1, rg ? rg->uses : -1, rs ? rs->uses : -1,
-                                (int) ggml_is_contiguous(dv), (int) ggml_is_contiguous(gr),
-                                (int) (gr->op == GGML_OP_GET_ROWS && gr->src[1]->data == as->data && gr->src[1]->nb[1] == as->nb[1] && gr->src[1]->ne[1] == as->ne[1]));
                     if (as->op == GGML_OP_ARGSORT && as->src[0] == node && as->op_params[0] == GGML_SORT_ORDER_DESC &&
                         gr->op == GGML_OP_GET_ROWS && root(gr->src[0]) == node && gr->src[0]->ne[0] == 1 && root(gr->src[1]) == as &&
                         gr->src[1]->data == as->data && gr->src[1]->nb[1] == as->nb[1] && gr->src[1]->ne[1] == as->ne[1] &&
@@ -1355,6 +1351,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                                 GGML_LOG_ERROR("MI355X MoE router(%s): %s\n", node->name, qmm_last_error());
                                 return GGML_STATUS_FAILED;
                             }
+                            if (dbg()) fprintf(stderr, "fused: moe router (%s)\n", node->name);
                             for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
                             continue;
                         }
@@ -1446,6 +1443,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                                         GGML_LOG_ERROR("MI355X rope + KV store + attention(%s): %s\n", node->name, qmm_last_error());
                                         return GGML_STATUS_FAILED;
                                     }
+                                    if (dbg()) fprintf(stderr, "fused: rope + kv store + attention (%s)\n", node->name);
                                     done[jk] = done[jck] = done[jcv] = 1;
                                     for (int j = 0; j < 5; ++j) done[idx[j]] = 1;
                                     continue;
