@@ -144,11 +144,12 @@ class LlamaBench:
                 _, err = self._run(["bench", "--gguf", gguf, "--ngl", "99", "-p", str(n_prompt), "-n", "64", "-r", "1", "-t", str(threads)],
                                    self._env(True, {"GGML_MI355X_TIMING": "1"}), timeout)
                 import re
-                m = re.search(r"tg graphs (\d+) stream_ms ([0-9.]+) \| pp graphs (\d+) tokens (\d+) stream_ms ([0-9.]+)", err)
+                m = re.search(r"tg graphs (\d+) stream_ms ([0-9.]+) \| pp graphs (\d+) tokens (\d+) stream_ms ([0-9.]+)(?: min_ms ([0-9.]+))?", err)
                 if m:
                     ntg, mtg, npp, tpp, mpp = int(m.group(1)), float(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5))
                     out["gpu_ms_per_token"] = round(mtg / max(ntg, 1), 4)
-                    out["gpu_ms_per_prompt_batch"] = round(mpp / max(npp, 1), 3)
+                    # the fastest prompt graph: the warm-up pass also re-lays weights at their first use (and loads code objects)
+                    out["gpu_ms_per_prompt_batch"] = round(float(m.group(6)) if m.group(6) else mpp / max(npp, 1), 3)
             return out
         except Exception as e:              # reported-only
             return {"pp512_tok_s": None, "tg128_tok_s": None, "threads": threads, "error": f"{type(e).__name__}: {str(e)[-300:]}"}

@@ -87,7 +87,7 @@ struct mi355x_backend_ctx {
     norm_req                         pending_norm;
     // GGML_MI355X_TIMING=1: stream time of every graph (an event pair around its launches), summed per kind of graph
     qmm_event *                      ev_t0 = nullptr, * ev_t1 = nullptr;
-    double                           ms_tg = 0, ms_pp = 0;
+    double                           ms_tg = 0, ms_pp = 0, ms_pp_min = 0;      // (min: the warm-up pass also repacks weights at their first use)
     int64_t                          graphs_tg = 0, graphs_pp = 0, tokens_pp = 0;
 };
 
@@ -1000,8 +1000,8 @@ void backend_free(ggml_backend_t backend) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     if (ctx->ev_copy) qmm_event_destroy(ctx->dev->qmm, ctx->ev_copy);
     if (ctx->ev_t0) {
-        fprintf(stderr, "MI355X timing %s: tg graphs %lld stream_ms %.3f | pp graphs %lld tokens %lld stream_ms %.3f\n", ctx->name.c_str(),
-                (long long) ctx->graphs_tg, ctx->ms_tg, (long long) ctx->graphs_pp, (long long) ctx->tokens_pp, ctx->ms_pp);
+        fprintf(stderr, "MI355X timing %s: tg graphs %lld stream_ms %.3f | pp graphs %lld tokens %lld stream_ms %.3f min_ms %.3f\n", ctx->name.c_str(),
+                (long long) ctx->graphs_tg, ctx->ms_tg, (long long) ctx->graphs_pp, (long long) ctx->tokens_pp, ctx->ms_pp, ctx->ms_pp_min);
         qmm_event_destroy(ctx->dev->qmm, ctx->ev_t0);
         qmm_event_destroy(ctx->dev->qmm, ctx->ev_t1);
     }
@@ -1541,7 +1541,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
             if (cgraph->nodes[i]->op == GGML_OP_MUL_MAT && cgraph->nodes[i]->ne[2] == 1) n_tok = std::max<int64_t>(n_tok, cgraph->nodes[i]->ne[1]);
         if (!qmm_event_elapsed_ms(ctx->dev->qmm, ctx->ev_t0, ctx->ev_t1, &ms)) {
             if (n_tok == 1) { ctx->ms_tg += ms; ctx->graphs_tg++; }
-            else { ctx->ms_pp += ms; ctx->graphs_pp++; ctx->tokens_pp += n_tok; }
+            else { ctx->ms_pp += ms; ctx->graphs_pp++; ctx->tokens_pp += n_tok; if (ctx->ms_pp_min == 0 || ms < ctx->ms_pp_min) ctx->ms_pp_min = ms; }
         }
     }
     return GGML_STATUS_SUCCESS;
