@@ -36,7 +36,7 @@ struct qmm_ctx {
     int64_t     mfma_calls = 0, mfma_checked = 0;   // prefill calls issued / covered by the last non-finite check (qmm_synchronize)
     bool        wide_attr_set = false;
     int         wide = 1;            // 256-token tiles for large Q4_K prefill launches (GGML_MI355X_WIDE=0: off)
-    int         r64 = 0;             // Q4_K prefill, 64 rows per wave + LDS DMA (mfma_r64_q4k_kernel): bit 0 = in place of the 256 x 128 kernel, bit 1 = in place of the 256 x 256 one (GGML_MI355X_R64)
+    int         r64 = 2;             // Q4_K prefill, 64 rows per wave + LDS DMA (mfma_r64_q4k_kernel): bit 0 = in place of the 256 x 128 kernel, bit 1 = in place of the 256 x 256 one (GGML_MI355X_R64)
     int         splitk = 1;          // split K over workgroups when a MUL_MAT has too few tiles (GGML_MI355X_SPLITK=0: off)
     // chains (qmm_chain.hiph): while recording, one-token MUL_MAT groups are collected instead of launched
     int         chain_enabled = 1;   // GGML_MI355X_CHAIN=0: qmm_chain_begin records nothing, every group is its own launch

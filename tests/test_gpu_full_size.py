@@ -162,7 +162,7 @@ def test_wide_tiles_equal_the_128_token_kernel(qmm, oracle):
 @pytest.fixture(scope="module")
 def qmm_by_r64():
     """contexts with the 64-rows-per-wave Q4_K prefill kernel off (0), in place of the 256 x 128 kernel (bit 0), in place of the
-    256 x 256 one (bit 1) and both (3); the switch is read when a context is created"""
+    256 x 256 one (bit 1: the default) and both (3); the switch is read when a context is created"""
     import os
     from ggml_hexagon_amd.capi import Qmm
     made, old = {}, os.environ.get("GGML_MI355X_R64")
