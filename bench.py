@@ -382,7 +382,7 @@ def main():
             "achieved": round(nb1 / s1 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb1 / s1 / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": traffic, "launches": c1, "avg_launch_us": round(s1 / c1 * 1e6, 2), "algo_bytes_per_launch": int(nb1 / c1),
             "all_tg_launches_GBs": round(sum(a[0] for a in agg1.values()) / sum(a[2] for a in agg1.values()) / 1e9, 1)}
-    pp_kernel = ("qmm::mfma_regb_q4k_wide_kernel<8> | mfma_regb_q4k_kernel<8,128>" if NAMES.get(kp[1]) == "q4_K" else f"qmm::mfma_regb_kernel<{NAMES.get(kp[1], kp[1])}>")
+    pp_kernel = ("qmm::mfma_r64_q4k_kernel<8> | mfma_regb_q4k_kernel<8,128>" if NAMES.get(kp[1]) == "q4_K" else f"qmm::mfma_regb_kernel<{NAMES.get(kp[1], kp[1])}>")
     roof_pp = {"bound": "mfma", "kernel": pp_kernel + " (+prep_act)",
                "achieved": round(flp / sp / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flp / sp / 1e12 / MFMA_PEAK_TFLOPS, 4),
                "launches": cp, "avg_launch_us": round(sp / cp * 1e6, 2)}
