@@ -1070,8 +1070,8 @@ void backend_synchronize(ggml_backend_t backend) {
         GGML_LOG_ERROR("MI355X synchronize: %s\n", qmm_last_error());
 }
 
-enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
-    auto * ctx = (mi355x_backend_ctx *) backend->context;
+// the analysis step of a graph_compute call
+void analyze_readers(mi355x_backend_ctx * ctx, const ggml_cgraph * cgraph) {
     // Reader analysis.  Candidates are the nodes a fusion wants to skip or move: RMS_NORM / SILU (fused into the MUL behind them),
     // kq / soft_max / kqv (the attention launch) and the quantized MUL_MATs (grouped with an earlier one on the same src1).
     // One pass over all operands records, per candidate, how many nodes of this graph read its memory (directly or through
@@ -1111,14 +1111,403 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
             }
         }
     }
-    auto info = [&](const ggml_tensor * t) -> const mi355x_backend_ctx::reader_info * {
+}
+
+// ---- one graph_compute call (analysis / plan / issue apart) -----------------------------------------------------------
+// analyze_readers() is the analysis; graph_pass holds what the launch sites share.  Every site_* looks at node i and returns 1 when it
+// issued (or deferred) the node, possibly together with later nodes that it marks in done[]; 0 when its pattern is not there (the
+// caller tries the next site, in the order below, and finally the node's own launch); -1 when a launch failed.
+struct graph_pass {
+    mi355x_backend_ctx * ctx;
+    ggml_cgraph * cgraph;
+    int n_nodes;
+    std::vector<char> & done;
+    std::vector<const ggml_tensor *> & deferred;
+    const mi355x_backend_ctx::reader_info * info(const ggml_tensor * t) const {
+        const auto & rd = ctx->readers;
         auto it = std::lower_bound(rd.begin(), rd.end(), t, [](const mi355x_backend_ctx::reader_info & x, const ggml_tensor * y) { return x.t < y; });
         return it != rd.end() && it->t == t ? &*it : nullptr;
-    };
-    auto single_use = [&](const ggml_tensor * t) {
+    }
+    bool single_use(const ggml_tensor * t) const {
         const auto * r = info(t);
         return r && r->uses == 1;
-    };
+    }
+    int site_deferred_silu_mul(int i, ggml_tensor * node, int gop);
+    int site_hold_silu(int i, ggml_tensor * node, int gop);
+    int site_add_rms_norm(int i, ggml_tensor * node, int gop);
+    int site_attention(int i, ggml_tensor * node, int gop);
+    int site_kqv_into_merged_heads(int i, ggml_tensor * node, int gop);
+    int site_moe_combine(int i, ggml_tensor * node, int gop);
+    int site_moe_router(int i, ggml_tensor * node, int gop);
+    int site_rope_kv_attention(int i, ggml_tensor * node, int gop);
+};
+
+// a MUL whose operand is a SILU that was held back (site_hold_silu): silu(gate) * up in one pass, or folded into the staging of the MUL_MAT behind it
+int graph_pass::site_deferred_silu_mul(int i, ggml_tensor * node, int gop) {
+    (void) gop;
+    enum ggml_status st;
+    if (deferred[i]) {
+        // MUL whose operand is a SILU that was held back: silu(gate) * up in one pass
+        const ggml_tensor * silu = deferred[i];
+        const ggml_tensor * gate = silu->src[0], * up = node->src[0] == silu ? node->src[1] : node->src[0];
+        // prompt batch, and the product feeds exactly one quantized MUL_MAT right behind it (ffn_down): that MUL_MAT's
+        // activation prep reads gate and up itself; no launch and no round trip for the product
+        int j = i + 1;
+        while (j < n_nodes && (done[j] || is_noop(cgraph->nodes[j]))) ++j;
+        if (j < n_nodes && node->ne[1] > QMM_MATVEC_MAX_N && node->ne[2] == 1 && node->ne[3] == 1 && single_use(node) &&
+            !(node->flags & GGML_TENSOR_FLAG_OUTPUT) && !getenv("GGML_MI355X_PREC")) {
+            const ggml_tensor * mm = cgraph->nodes[j], * w = mm->src[0];
+            const qmm_tensor qg = to_qt(gate, ctx), qu = to_qt(up, ctx);      // resolved now: a redirect may expire before node j
+            if (mm->op == GGML_OP_MUL_MAT && !glue_op(mm) && mm->src[1] == node && supports_mul_mat(mm) && is_ours(w) && !is_split(w) &&
+                w->ne[2] == 1 && w->ne[3] == 1 && gate->nb[0] == 4 && up->nb[0] == 4 && gate->nb[1] % 16 == 0 && up->nb[1] % 16 == 0 &&
+                (uintptr_t) qg.data % 16 == 0 && (uintptr_t) qu.data % 16 == 0) {
+                ctx->swiglu_in[j] = { (const float *) qg.data, (const float *) qu.data, (int64_t) (gate->nb[1] / 4), (int64_t) (up->nb[1] / 4) };
+                return 1;
+            }
+        }
+        st = compute_glue(ctx, node, QMM_OP_SILU_MUL, gate, up, nullptr);
+        if (st != GGML_STATUS_SUCCESS) return -1;
+        return 1;
+    }
+    return 0;
+}
+
+// SILU read by one MUL further down (build_ffn: gate, silu, up, mul): held back for that MUL
+int graph_pass::site_hold_silu(int i, ggml_tensor * node, int gop) {
+    (void) gop;
+    const ggml_tensor * other = nullptr;
+    if (node->op == GGML_OP_UNARY && ggml_get_unary_op(node) == GGML_UNARY_OP_SILU && single_use(node)) {
+        // find the MUL that reads it (build_ffn: gate, silu, up, mul): hold the SILU back when nothing in between
+        // writes over its input
+        int j = i + 1;
+        bool safe = true;
+        for (; j < n_nodes && j <= i + LOOKAHEAD; ++j) {
+            const ggml_tensor * t = cgraph->nodes[j];
+            if (t->src[0] == node || t->src[1] == node) break;
+            if (!done[j] && !is_noop(t) && ranges_overlap(t, node->src[0])) safe = false;
+        }
+        if (safe && j < n_nodes && j <= i + LOOKAHEAD && fused_pair(node, cgraph->nodes[j], &other) == QMM_OP_SILU_MUL) {
+            deferred[j] = node;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+// residual ADD -> RMS_NORM -> MUL(w): one launch with two results
+int graph_pass::site_add_rms_norm(int i, ggml_tensor * node, int gop) {
+    (void) gop;
+    const ggml_tensor * other = nullptr;
+    if (node->op == GGML_OP_ADD && i + 2 < n_nodes && !GGML_MI355X_FUSE_OFF()) {
+        // residual add -> RMS_NORM -> MUL by the norm weight: one pass with two results
+        ggml_tensor * rn = cgraph->nodes[i + 1], * mul = cgraph->nodes[i + 2];
+        if (rn->op == GGML_OP_RMS_NORM && rn->src[0] == node && single_use(rn) && fused_pair(rn, mul, &other) == QMM_OP_RMS_NORM_MUL) {
+            const qmm_tensor a = to_qt(node->src[0], ctx), b = to_qt(node->src[1], ctx), w = to_qt(other, ctx), sum = to_qt(node, ctx), d = to_qt(mul, ctx);
+            // `mul`'s buffer is written two nodes early: it may be the block of an ADD operand that dies here (same rows: fine, a
+            // workgroup holds its row in registers before it stores; anything else: keep the graph's order)
+            const bool e_ok = early_write_ok(mul, { node->src[0], node->src[1], other, node }, nullptr) ||
+                              (early_write_ok(mul, { node->src[1], other, node }, nullptr) && early_write_ok(mul, { node->src[0] }, node->src[0])) ||
+                              (early_write_ok(mul, { node->src[0], other, node }, nullptr) && early_write_ok(mul, { node->src[1] }, node->src[1]));
+            if (e_ok && qmm_op_add_rms_norm_supported(&a, &b, &w, &sum, &d)) {
+                float eps;
+                memcpy(&eps, rn->op_params, sizeof(float));
+                if (qmm_op_add_rms_norm(ctx->dev->qmm, &a, &b, &w, &sum, &d, eps, qmm_stream(ctx->dev->qmm))) {
+                    GGML_LOG_ERROR("MI355X ADD+RMS_NORM(%s): %s\n", node->name, qmm_last_error());
+                    return -1;
+                }
+                done[i + 1] = done[i + 2] = 1;
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+// kq -> soft_max -> kqv -> permute -> cont (build_attn_mha) as one launch
+int graph_pass::site_attention(int i, ggml_tensor * node, int gop) {
+    (void) gop;
+    if (gop == QMM_OP_MUL_MAT_F && node->src[0]->type == GGML_TYPE_F16 && single_use(node) && !GGML_MI355X_FUSE_OFF()) {
+        // kq -> soft_max -> kqv -> permute -> cont (build_attn_mha): one launch, for a few tokens (qmm_attn_decode) and for prompt
+        // batches whose scores fit LDS (qmm_attn_prefill)
+        int idx[4], k = 0;
+        for (int j = i + 1; j < n_nodes && j <= i + 8 && k < 4; ++j) {
+            const ggml_tensor * t = cgraph->nodes[j];
+            if (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_TRANSPOSE) continue;
+            idx[k++] = j;
+        }
+        if (k == 4) {
+            ggml_tensor * sm = cgraph->nodes[idx[0]], * kqv = cgraph->nodes[idx[1]], * pm = cgraph->nodes[idx[2]], * ct = cgraph->nodes[idx[3]];
+            float scale, max_bias;
+            memcpy(&scale, (const float *) sm->op_params + 0, sizeof(float));
+            memcpy(&max_bias, (const float *) sm->op_params + 1, sizeof(float));
+            if (sm->op == GGML_OP_SOFT_MAX && sm->src[0] == node && sm->src[1] && max_bias == 0.0f && single_use(sm) &&
+                kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm && kqv->src[0]->type == GGML_TYPE_F16 && single_use(kqv) &&
+                pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv && pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] &&
+                pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm &&
+                ((early_write_ok(ct, { node->src[0], kqv->src[0], sm->src[1] }) && early_write_ok(ct, { node->src[1] }, node->src[1], true)) ||
+                 hoist_elsewhere(ctx, ct))) {      // ggml-alloc puts ct across the dead Q blocks in llama.cpp's layers: written to the scratch instead, wo reads it there
+                const qmm_tensor q = to_qt(node->src[1], ctx), kk = to_qt(node->src[0], ctx), v = to_qt(kqv->src[0], ctx), m = to_qt(sm->src[1], ctx), d = to_qt(ct, ctx);
+                const bool few = qmm_attn_decode_supported(&q, &kk, &v, &m, &d) != 0;
+                if (few || qmm_attn_prefill_supported(&q, &kk, &v, &m, &d)) {
+                    if (few ? qmm_attn_decode(ctx->dev->qmm, &q, &kk, &v, &m, &d, scale, qmm_stream(ctx->dev->qmm))
+                            : qmm_attn_prefill(ctx->dev->qmm, &q, &kk, &v, &m, &d, scale, qmm_stream(ctx->dev->qmm))) {
+                        GGML_LOG_ERROR("MI355X attention(%s): %s\n", node->name, qmm_last_error());
+                        return -1;
+                    }
+                    if (dbg()) fprintf(stderr, "fused: attention (%s, %s)\n", few ? "few tokens" : "prompt", node->name);
+                    for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
+                    return 1;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+// kqv -> permute -> cont: the product written straight into the merged-heads layout
+int graph_pass::site_kqv_into_merged_heads(int i, ggml_tensor * node, int gop) {
+    (void) gop;
+    if (gop == QMM_OP_MUL_MAT_F && node->src[0]->type == GGML_TYPE_F16 && single_use(node) && !GGML_MI355X_FUSE_OFF() && !done[i]) {
+        // kqv -> permute(0, 2, 1, 3) -> cont (build_attn_mha's head merge) at any batch size: the product is written
+        // straight into the cont's layout (dst strides of dims 1 and 2 swapped), the copy never runs
+        int jp = i + 1;
+        while (jp < n_nodes && (cgraph->nodes[jp]->op == GGML_OP_RESHAPE || cgraph->nodes[jp]->op == GGML_OP_VIEW)) ++jp;
+        int jc = jp + 1;
+        while (jc < n_nodes && (cgraph->nodes[jc]->op == GGML_OP_RESHAPE || cgraph->nodes[jc]->op == GGML_OP_VIEW)) ++jc;
+        if (jc < n_nodes) {
+            const ggml_tensor * pm = cgraph->nodes[jp], * ct = cgraph->nodes[jc];
+            if (pm->op == GGML_OP_PERMUTE && pm->src[0] == node && ct->op == GGML_OP_CONT && ct->src[0] == pm && !done[jc] &&
+                pm->ne[0] == node->ne[0] && pm->ne[1] == node->ne[2] && pm->ne[2] == node->ne[1] && node->ne[3] == 1 &&
+                ct->type == GGML_TYPE_F32 && ggml_is_contiguous(ct) && ggml_nelements(ct) == ggml_nelements(node) &&
+                early_write_ok(ct, { node->src[0], node->src[1] })) {
+                qmm_tensor d = to_qt(node, ctx);
+                d.data = to_qt(ct, ctx).data;                                 // element (d, n, h) of kqv = element (d, h, n) of the merged result (ct may live in the scratch)
+                d.nb[1] = (int64_t) node->ne[0] * node->ne[2] * 4;
+                d.nb[2] = (int64_t) node->ne[0] * 4;
+                d.nb[3] = (int64_t) ggml_nbytes(ct);
+                const qmm_tensor a = to_qt(node->src[0], ctx), b = to_qt(node->src[1], ctx);
+                if (qmm_op_supported(QMM_OP_MUL_MAT_F, &a, &b, nullptr, &d)) {
+                    if (qmm_op_compute(ctx->dev->qmm, QMM_OP_MUL_MAT_F, &a, &b, nullptr, &d, qmm_stream(ctx->dev->qmm))) {
+                        GGML_LOG_ERROR("MI355X MUL_MAT(%s) into merged heads: %s\n", node->name, qmm_last_error());
+                        return -1;
+                    }
+                    done[jc] = 1;
+                    return 1;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+// experts * weights and the sum over the used experts (build_moe_ffn's tail): one launch
+int graph_pass::site_moe_combine(int i, ggml_tensor * node, int gop) {
+    (void) gop;
+    if (node->op == GGML_OP_MUL && node->src[1]->ne[0] == 1 && node->ne[1] >= 2 && node->ne[1] == node->src[1]->ne[1] && node->ne[3] == 1 &&
+        !GGML_MI355X_FUSE_OFF()) {
+        // experts * weights and the sum over the used experts through 2-D views (build_moe_ffn's tail): one launch
+        const int U = (int) node->ne[1];
+        const auto * rm = info(node);
+        int idx[64], k = 0;
+        for (int j = i + 1; j < n_nodes && j <= i + 4 * U + 4 && k < U - 1; ++j) {
+            const ggml_tensor * t = cgraph->nodes[j];
+            if (done[j] || is_noop(t)) continue;
+            if (t->op != GGML_OP_ADD) break;
+            idx[k++] = j;
+        }
+        const auto root = [](const ggml_tensor * t) { return t->view_src ? t->view_src : t; };
+        const auto is_slice = [&](const ggml_tensor * v, int u) {           // view_2d(experts, E, N, nb[2], u * nb[1])
+            return root(v) == node && v->ne[0] == node->ne[0] && v->ne[1] == node->ne[2] && v->ne[2] == 1 && v->nb[1] == node->nb[2] &&
+                   (const char *) v->data == (const char *) node->data + (size_t) u * node->nb[1];
+        };
+        bool ok = k == U - 1 && rm && rm->uses == U && U <= 64 && !(node->flags & GGML_TENSOR_FLAG_OUTPUT);
+        for (int a = 0; ok && a < U - 1; ++a) {
+            const ggml_tensor * ad = cgraph->nodes[idx[a]];
+            ok = is_slice(ad->src[1], a + 1) && (a == 0 ? is_slice(ad->src[0], 0) : ad->src[0] == cgraph->nodes[idx[a - 1]]) &&
+                 (a == U - 2 || (single_use(ad) && !(ad->flags & GGML_TENSOR_FLAG_OUTPUT)));
+        }
+        if (ok) {
+            const ggml_tensor * last = cgraph->nodes[idx[U - 2]];
+            const qmm_tensor x = to_qt(node->src[0], ctx), w = to_qt(node->src[1], ctx), o = to_qt(last, ctx);
+            if (qmm_moe_combine_supported(&x, &w, &o)) {
+                if (qmm_moe_combine(ctx->dev->qmm, &x, &w, &o, qmm_stream(ctx->dev->qmm))) {
+                    GGML_LOG_ERROR("MI355X MoE combine(%s): %s\n", node->name, qmm_last_error());
+                    return -1;
+                }
+                for (int a = 0; a < U - 1; ++a) done[idx[a]] = 1;
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+// soft_max -> argsort -> get_rows -> sum_rows -> div behind the router logits: one launch
+int graph_pass::site_moe_router(int i, ggml_tensor * node, int gop) {
+    (void) gop;
+    if (node->op == GGML_OP_SOFT_MAX && !node->src[1] && node->ne[0] <= 64 && node->ne[2] == 1 && node->ne[3] == 1 && !GGML_MI355X_FUSE_OFF()) {
+        // the MoE router behind its logits (build_moe_ffn): soft_max -> argsort (top_k view) -> get_rows -> sum_rows -> div
+        float scale, max_bias;
+        memcpy(&scale, (const float *) node->op_params + 0, sizeof(float));
+        memcpy(&max_bias, (const float *) node->op_params + 1, sizeof(float));
+        // llama.cpp's graph order puts get_rows / sum_rows / div (the weights, needed only by the final mul) BEHIND the expert
+        // MUL_MAT_IDs: the argsort follows the soft_max directly, the other three are looked for further down and run here,
+        // early (their inputs exist; where the div's buffer is still in use at this point the weights go to the scratch)
+        const auto root = [](const ggml_tensor * t) { return t->view_src ? t->view_src : t; };
+        int idx[4], k = 0;
+        std::vector<const ggml_tensor *> & skipped = ctx->skipped;
+        skipped.clear();
+        for (int j = i + 1; j < n_nodes && j <= i + 64 && k < 4; ++j) {
+            const ggml_tensor * t = cgraph->nodes[j];
+            if (done[j] || is_noop(t)) continue;
+            const bool want = (k == 0 && t->op == GGML_OP_ARGSORT && t->src[0] == node) ||
+                              (k == 1 && t->op == GGML_OP_GET_ROWS && root(t->src[0]) == node && root(t->src[1]) == cgraph->nodes[idx[0]]) ||
+                              (k == 2 && t->op == GGML_OP_SUM_ROWS && root(t->src[0]) == cgraph->nodes[idx[1]]) ||
+                              (k == 3 && t->op == GGML_OP_DIV && root(t->src[0]) == cgraph->nodes[idx[1]] && t->src[1] == cgraph->nodes[idx[2]]);
+            if (want) idx[k++] = j;
+            else if (k == 0) break;                                             // the argsort must come first
+            else skipped.push_back(t);
+        }
+        if (k == 4 && scale == 1.0f && max_bias == 0.0f) {
+            ggml_tensor * as = cgraph->nodes[idx[0]], * gr = cgraph->nodes[idx[1]], * sr = cgraph->nodes[idx[2]], * dv = cgraph->nodes[idx[3]];
+            const auto * ri = info(node), * rg = info(gr), * rs = info(sr);
+            if (as->op == GGML_OP_ARGSORT && as->src[0] == node && as->op_params[0] == GGML_SORT_ORDER_DESC &&
+                gr->op == GGML_OP_GET_ROWS && root(gr->src[0]) == node && gr->src[0]->ne[0] == 1 && root(gr->src[1]) == as &&
+                gr->src[1]->data == as->data && gr->src[1]->nb[1] == as->nb[1] && gr->src[1]->ne[1] == as->ne[1] &&
+                sr->op == GGML_OP_SUM_ROWS && root(sr->src[0]) == gr && dv->op == GGML_OP_DIV && root(dv->src[0]) == gr && dv->src[1] == sr &&
+                ri && ri->uses == 2 && rg && rg->uses == 2 && rs && rs->uses == 1 && ggml_is_contiguous(dv) && ggml_is_contiguous(gr) &&
+                !(node->flags & GGML_TENSOR_FLAG_OUTPUT) && !(gr->flags & GGML_TENSOR_FLAG_OUTPUT) && !(sr->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                const int64_t n_used = gr->src[1]->ne[0];
+                // the weights are written now, not at the div's place in the graph: its block must be free here
+                if (!can_hoist(dv, skipped) && !hoist_elsewhere(ctx, dv)) return 0;
+                const qmm_tensor lg = to_qt(node->src[0], ctx), ids = to_qt(as, ctx), w = to_qt(dv, ctx);
+                if (qmm_moe_router_supported(&lg, &ids, &w, n_used)) {
+                    if (qmm_moe_router(ctx->dev->qmm, &lg, &ids, &w, n_used, 1, qmm_stream(ctx->dev->qmm))) {
+                        GGML_LOG_ERROR("MI355X MoE router(%s): %s\n", node->name, qmm_last_error());
+                        return -1;
+                    }
+                    if (dbg()) fprintf(stderr, "fused: moe router (%s)\n", node->name);
+                    for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
+                    return 1;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+// rope(q) with rope(k) -> K cache, v -> V cache and, for a few tokens, the attention: one launch
+int graph_pass::site_rope_kv_attention(int i, ggml_tensor * node, int gop) {
+    (void) gop;
+    if (node->op == GGML_OP_ROPE && !GGML_MI355X_FUSE_OFF()) {
+        // rope(q) with, from further down the graph, rope(k) -> K cache and v -> V cache (build_attn's two ggml_cpy): one launch
+        // (any batch size: at 512 tokens 29 us of four launches become one, pp512 31.2k -> 32.0k).
+        // Their inputs must exist already (k and v were hoisted into the q/k/v group); the cache is not compute-buffer
+        // memory, so storing early cannot collide with anything in between.
+        auto ready = [&](const ggml_tensor * t) {                            // was t's root produced before this point?
+            const ggml_tensor * root = t->view_src ? t->view_src : t;
+            for (int j = i + 1; j < n_nodes && j <= i + 2 * LOOKAHEAD; ++j)
+                if (cgraph->nodes[j] == root) return done[j] != 0;
+            return true;
+        };
+        int jk = -1, jck = -1, jcv = -1;
+        for (int j = i + 1; j < n_nodes && j <= i + 2 * LOOKAHEAD; ++j) {
+            const ggml_tensor * t = cgraph->nodes[j];
+            if (done[j] || is_noop(t)) continue;
+            if (jk < 0 && t->op == GGML_OP_ROPE && t->src[1] == node->src[1] && t->src[2] == node->src[2] && t->ne[0] == node->ne[0] &&
+                !memcmp(t->op_params, node->op_params, sizeof(t->op_params)) && t->type == GGML_TYPE_F32 && ggml_is_contiguous(t) &&
+                single_use(t) && ready(t->src[0])) {
+                jk = j;
+            } else if (jk >= 0 && jck < 0 && t->op == GGML_OP_CPY && t->src[0] == cgraph->nodes[jk] && t->type == GGML_TYPE_F16 && ggml_is_contiguous(t)) {
+                jck = j;
+            } else if (jcv < 0 && t->op == GGML_OP_CPY && t->type == GGML_TYPE_F16 && t->src[0]->type == GGML_TYPE_F32 &&
+                       (t->src[0]->view_src ? t->src[0]->view_src : t->src[0])->op == GGML_OP_MUL_MAT && ready(t->src[0]) &&
+                       (jk < 0 || t->src[0] != cgraph->nodes[jk])) {
+                jcv = j;
+            } else if (t->op == GGML_OP_MUL_MAT || t->op == GGML_OP_SOFT_MAX) {
+                break;                                                         // attention starts: nothing to find beyond
+            }
+        }
+        if (jk >= 0 && jck < 0) jk = -1;                                       // rope(k) without its store stays where it is
+        if (jk >= 0 || jcv >= 0) {
+            const qmm_tensor q = to_qt(node->src[0], ctx), pos = to_qt(node->src[1], ctx), qd = to_qt(node, ctx);
+            qmm_tensor ff{}, k{}, kd{}, v{}, vd{};
+            if (node->src[2]) ff = to_qt(node->src[2], ctx);
+            if (jk >= 0) {
+                const ggml_tensor * rk = cgraph->nodes[jk];
+                k = to_qt(rk->src[0], ctx);
+                kd = to_qt(rk, ctx);                                           // shape of rope(k), bytes of the cache view
+                kd.data = cgraph->nodes[jck]->data;
+                kd.type = GGML_TYPE_F16;
+                kd.nb[0] = 2;
+                for (int a = 1; a < 4; ++a) kd.nb[a] = kd.nb[a - 1] * kd.ne[a - 1];
+            }
+            if (jcv >= 0) {
+                v = to_qt(cgraph->nodes[jcv]->src[0], ctx);
+                vd = to_qt(cgraph->nodes[jcv], ctx);
+            }
+            const qmm_tensor * pff = node->src[2] ? &ff : nullptr, * pk = jk >= 0 ? &k : nullptr, * pkd = jk >= 0 ? &kd : nullptr,
+                             * pv = jcv >= 0 ? &v : nullptr, * pvd = jcv >= 0 ? &vd : nullptr;
+            // ... and when the attention chain follows (few tokens): rope, KV store and attention in one launch
+            // (GGML_MI355X_ATTN_ROPE=0: two launches; tg128 395 -> 403 tok/s)
+            if (jk >= 0 && jcv >= 0 && node->ne[2] <= 8 && single_use(node) && GGML_MI355X_ATTN_ROPE()) {
+                int idx[5], kq_n = 0;
+                for (int j = std::max(jck, jcv) + 1; j < n_nodes && j <= i + 4 * LOOKAHEAD && kq_n < 5; ++j) {
+                    const ggml_tensor * t = cgraph->nodes[j];
+                    if (done[j] || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_TRANSPOSE) continue;
+                    if (kq_n == 0 && t->op == GGML_OP_PERMUTE) continue;                   // q's permute in front of kq
+                    idx[kq_n++] = j;
+                }
+                if (kq_n == 5) {
+                    ggml_tensor * kqn = cgraph->nodes[idx[0]], * sm = cgraph->nodes[idx[1]], * kqv = cgraph->nodes[idx[2]], * pm = cgraph->nodes[idx[3]],
+                                * ct = cgraph->nodes[idx[4]];
+                    float scale, max_bias;
+                    memcpy(&scale, (const float *) sm->op_params + 0, sizeof(float));
+                    memcpy(&max_bias, (const float *) sm->op_params + 1, sizeof(float));
+                    if (kqn->op == GGML_OP_MUL_MAT && kqn->src[0]->type == GGML_TYPE_F16 && kqn->src[1]->op == GGML_OP_PERMUTE &&
+                        kqn->src[1]->src[0] == node && single_use(kqn) && sm->op == GGML_OP_SOFT_MAX && sm->src[0] == kqn && sm->src[1] &&
+                        max_bias == 0.0f && single_use(sm) && kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm &&
+                        kqv->src[0]->type == GGML_TYPE_F16 && single_use(kqv) && pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv &&
+                        pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] && pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm &&
+                        ((early_write_ok(ct, { node->src[1], node->src[2], cgraph->nodes[jk]->src[0], cgraph->nodes[jcv]->src[0],
+                                               kqn->src[0], kqv->src[0], sm->src[1] }) &&
+                          early_write_ok(ct, { node->src[0] }, node->src[0], true) && early_write_ok(ct, { node }, node, true)) ||
+                         hoist_elsewhere(ctx, ct))) {
+                        const qmm_tensor kc = to_qt(kqn->src[0], ctx), vc = to_qt(kqv->src[0], ctx), m = to_qt(sm->src[1], ctx), d = to_qt(ct, ctx);
+                        const int64_t off = (const char *) kd.data - (const char *) kc.data;
+                        const int64_t j0 = kc.nb[1] > 0 && off >= 0 && off % kc.nb[1] == 0 ? off / kc.nb[1] : -1;
+                        const bool v_ok = (const char *) vd.data - (const char *) vc.data == j0 * 2;
+                        if (j0 >= 0 && v_ok && qmm_attn_decode_rope_supported(&q, &pos, pff, &qd, &k, &kd, &v, &vd, &kc, &vc, &m, &d, j0)) {
+                            if (qmm_attn_decode_rope(ctx->dev->qmm, &q, &pos, pff, &qd, &k, &kd, &v, &vd, &kc, &vc, &m, &d, scale, j0,
+                                                     qmm_stream(ctx->dev->qmm))) {
+                                GGML_LOG_ERROR("MI355X rope + KV store + attention(%s): %s\n", node->name, qmm_last_error());
+                                return -1;
+                            }
+                            if (dbg()) fprintf(stderr, "fused: rope + kv store + attention (%s)\n", node->name);
+                            done[jk] = done[jck] = done[jcv] = 1;
+                            for (int j = 0; j < 5; ++j) done[idx[j]] = 1;
+                            return 1;
+                        }
+                    }
+                }
+            }
+            if (qmm_rope_kv_store_supported(&q, &pos, pff, &qd, pk, pkd, pv, pvd)) {
+                if (qmm_rope_kv_store(ctx->dev->qmm, &q, &pos, pff, &qd, pk, pkd, pv, pvd, qmm_stream(ctx->dev->qmm))) {
+                    GGML_LOG_ERROR("MI355X rope + KV store(%s): %s\n", node->name, qmm_last_error());
+                    return -1;
+                }
+                if (jk >= 0) done[jk] = done[jck] = 1;
+                if (jcv >= 0) done[jcv] = 1;
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
+    auto * ctx = (mi355x_backend_ctx *) backend->context;
+    analyze_readers(ctx, cgraph);
     const int n_nodes = cgraph->n_nodes;
     const bool timing = GGML_MI355X_TIMING();
     if (timing) {
@@ -1139,6 +1528,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
     std::vector<const ggml_tensor *> & deferred = ctx->deferred;
     deferred.assign(n_nodes, nullptr);
     ctx->swiglu_in.assign(n_nodes, {});
+    graph_pass P{ ctx, cgraph, n_nodes, done, deferred };
     for (int i = 0; i < n_nodes; ++i) {
         struct ggml_tensor * node = cgraph->nodes[i];
         if (done[i] || is_noop(node)) continue;                                      // ggml-hexagon.cpp:5561-5566
@@ -1149,325 +1539,23 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         if (gop) {
             const ggml_tensor * other = nullptr;
             int fop = 0;
-            if (deferred[i]) {
-                // MUL whose operand is a SILU that was held back: silu(gate) * up in one pass
-                const ggml_tensor * silu = deferred[i];
-                const ggml_tensor * gate = silu->src[0], * up = node->src[0] == silu ? node->src[1] : node->src[0];
-                // prompt batch, and the product feeds exactly one quantized MUL_MAT right behind it (ffn_down): that MUL_MAT's
-                // activation prep reads gate and up itself; no launch and no round trip for the product
-                int j = i + 1;
-                while (j < n_nodes && (done[j] || is_noop(cgraph->nodes[j]))) ++j;
-                if (j < n_nodes && node->ne[1] > QMM_MATVEC_MAX_N && node->ne[2] == 1 && node->ne[3] == 1 && single_use(node) &&
-                    !(node->flags & GGML_TENSOR_FLAG_OUTPUT) && !getenv("GGML_MI355X_PREC")) {
-                    const ggml_tensor * mm = cgraph->nodes[j], * w = mm->src[0];
-                    const qmm_tensor qg = to_qt(gate, ctx), qu = to_qt(up, ctx);      // resolved now: a redirect may expire before node j
-                    if (mm->op == GGML_OP_MUL_MAT && !glue_op(mm) && mm->src[1] == node && supports_mul_mat(mm) && is_ours(w) && !is_split(w) &&
-                        w->ne[2] == 1 && w->ne[3] == 1 && gate->nb[0] == 4 && up->nb[0] == 4 && gate->nb[1] % 16 == 0 && up->nb[1] % 16 == 0 &&
-                        (uintptr_t) qg.data % 16 == 0 && (uintptr_t) qu.data % 16 == 0) {
-                        ctx->swiglu_in[j] = { (const float *) qg.data, (const float *) qu.data, (int64_t) (gate->nb[1] / 4), (int64_t) (up->nb[1] / 4) };
-                        continue;
-                    }
-                }
-                st = compute_glue(ctx, node, QMM_OP_SILU_MUL, gate, up, nullptr);
-                if (st != GGML_STATUS_SUCCESS) return st;
-                continue;
-            }
-            if (node->op == GGML_OP_UNARY && ggml_get_unary_op(node) == GGML_UNARY_OP_SILU && single_use(node)) {
-                // find the MUL that reads it (build_ffn: gate, silu, up, mul): hold the SILU back when nothing in between
-                // writes over its input
-                int j = i + 1;
-                bool safe = true;
-                for (; j < n_nodes && j <= i + LOOKAHEAD; ++j) {
-                    const ggml_tensor * t = cgraph->nodes[j];
-                    if (t->src[0] == node || t->src[1] == node) break;
-                    if (!done[j] && !is_noop(t) && ranges_overlap(t, node->src[0])) safe = false;
-                }
-                if (safe && j < n_nodes && j <= i + LOOKAHEAD && fused_pair(node, cgraph->nodes[j], &other) == QMM_OP_SILU_MUL) {
-                    deferred[j] = node;
-                    continue;
-                }
-            }
-            if (node->op == GGML_OP_ADD && i + 2 < n_nodes && !GGML_MI355X_FUSE_OFF()) {
-                // residual add -> RMS_NORM -> MUL by the norm weight: one pass with two results
-                ggml_tensor * rn = cgraph->nodes[i + 1], * mul = cgraph->nodes[i + 2];
-                if (rn->op == GGML_OP_RMS_NORM && rn->src[0] == node && single_use(rn) && fused_pair(rn, mul, &other) == QMM_OP_RMS_NORM_MUL) {
-                    const qmm_tensor a = to_qt(node->src[0], ctx), b = to_qt(node->src[1], ctx), w = to_qt(other, ctx), sum = to_qt(node, ctx), d = to_qt(mul, ctx);
-                    // `mul`'s buffer is written two nodes early: it may be the block of an ADD operand that dies here (same rows: fine, a
-                    // workgroup holds its row in registers before it stores; anything else: keep the graph's order)
-                    const bool e_ok = early_write_ok(mul, { node->src[0], node->src[1], other, node }, nullptr) ||
-                                      (early_write_ok(mul, { node->src[1], other, node }, nullptr) && early_write_ok(mul, { node->src[0] }, node->src[0])) ||
-                                      (early_write_ok(mul, { node->src[0], other, node }, nullptr) && early_write_ok(mul, { node->src[1] }, node->src[1]));
-                    if (e_ok && qmm_op_add_rms_norm_supported(&a, &b, &w, &sum, &d)) {
-                        float eps;
-                        memcpy(&eps, rn->op_params, sizeof(float));
-                        if (qmm_op_add_rms_norm(ctx->dev->qmm, &a, &b, &w, &sum, &d, eps, qmm_stream(ctx->dev->qmm))) {
-                            GGML_LOG_ERROR("MI355X ADD+RMS_NORM(%s): %s\n", node->name, qmm_last_error());
-                            return GGML_STATUS_FAILED;
-                        }
-                        done[i + 1] = done[i + 2] = 1;
-                        continue;
-                    }
-                }
-            }
-            if (gop == QMM_OP_MUL_MAT_F && node->src[0]->type == GGML_TYPE_F16 && single_use(node) && !GGML_MI355X_FUSE_OFF()) {
-                // kq -> soft_max -> kqv -> permute -> cont (build_attn_mha): one launch, for a few tokens (qmm_attn_decode) and for prompt
-                // batches whose scores fit LDS (qmm_attn_prefill)
-                int idx[4], k = 0;
-                for (int j = i + 1; j < n_nodes && j <= i + 8 && k < 4; ++j) {
-                    const ggml_tensor * t = cgraph->nodes[j];
-                    if (t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_TRANSPOSE) continue;
-                    idx[k++] = j;
-                }
-                if (k == 4) {
-                    ggml_tensor * sm = cgraph->nodes[idx[0]], * kqv = cgraph->nodes[idx[1]], * pm = cgraph->nodes[idx[2]], * ct = cgraph->nodes[idx[3]];
-                    float scale, max_bias;
-                    memcpy(&scale, (const float *) sm->op_params + 0, sizeof(float));
-                    memcpy(&max_bias, (const float *) sm->op_params + 1, sizeof(float));
-                    if (sm->op == GGML_OP_SOFT_MAX && sm->src[0] == node && sm->src[1] && max_bias == 0.0f && single_use(sm) &&
-                        kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm && kqv->src[0]->type == GGML_TYPE_F16 && single_use(kqv) &&
-                        pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv && pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] &&
-                        pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm &&
-                        ((early_write_ok(ct, { node->src[0], kqv->src[0], sm->src[1] }) && early_write_ok(ct, { node->src[1] }, node->src[1], true)) ||
-                         hoist_elsewhere(ctx, ct))) {      // ggml-alloc puts ct across the dead Q blocks in llama.cpp's layers: written to the scratch instead, wo reads it there
-                        const qmm_tensor q = to_qt(node->src[1], ctx), kk = to_qt(node->src[0], ctx), v = to_qt(kqv->src[0], ctx), m = to_qt(sm->src[1], ctx), d = to_qt(ct, ctx);
-                        const bool few = qmm_attn_decode_supported(&q, &kk, &v, &m, &d) != 0;
-                        if (few || qmm_attn_prefill_supported(&q, &kk, &v, &m, &d)) {
-                            if (few ? qmm_attn_decode(ctx->dev->qmm, &q, &kk, &v, &m, &d, scale, qmm_stream(ctx->dev->qmm))
-                                    : qmm_attn_prefill(ctx->dev->qmm, &q, &kk, &v, &m, &d, scale, qmm_stream(ctx->dev->qmm))) {
-                                GGML_LOG_ERROR("MI355X attention(%s): %s\n", node->name, qmm_last_error());
-                                return GGML_STATUS_FAILED;
-                            }
-                            if (dbg()) fprintf(stderr, "fused: attention (%s, %s)\n", few ? "few tokens" : "prompt", node->name);
-                            for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
-                            continue;
-                        }
-                    }
-                }
-            }
-            if (gop == QMM_OP_MUL_MAT_F && node->src[0]->type == GGML_TYPE_F16 && single_use(node) && !GGML_MI355X_FUSE_OFF() && !done[i]) {
-                // kqv -> permute(0, 2, 1, 3) -> cont (build_attn_mha's head merge) at any batch size: the product is written
-                // straight into the cont's layout (dst strides of dims 1 and 2 swapped), the copy never runs
-                int jp = i + 1;
-                while (jp < n_nodes && (cgraph->nodes[jp]->op == GGML_OP_RESHAPE || cgraph->nodes[jp]->op == GGML_OP_VIEW)) ++jp;
-                int jc = jp + 1;
-                while (jc < n_nodes && (cgraph->nodes[jc]->op == GGML_OP_RESHAPE || cgraph->nodes[jc]->op == GGML_OP_VIEW)) ++jc;
-                if (jc < n_nodes) {
-                    const ggml_tensor * pm = cgraph->nodes[jp], * ct = cgraph->nodes[jc];
-                    if (pm->op == GGML_OP_PERMUTE && pm->src[0] == node && ct->op == GGML_OP_CONT && ct->src[0] == pm && !done[jc] &&
-                        pm->ne[0] == node->ne[0] && pm->ne[1] == node->ne[2] && pm->ne[2] == node->ne[1] && node->ne[3] == 1 &&
-                        ct->type == GGML_TYPE_F32 && ggml_is_contiguous(ct) && ggml_nelements(ct) == ggml_nelements(node) &&
-                        early_write_ok(ct, { node->src[0], node->src[1] })) {
-                        qmm_tensor d = to_qt(node, ctx);
-                        d.data = to_qt(ct, ctx).data;                                 // element (d, n, h) of kqv = element (d, h, n) of the merged result (ct may live in the scratch)
-                        d.nb[1] = (int64_t) node->ne[0] * node->ne[2] * 4;
-                        d.nb[2] = (int64_t) node->ne[0] * 4;
-                        d.nb[3] = (int64_t) ggml_nbytes(ct);
-                        const qmm_tensor a = to_qt(node->src[0], ctx), b = to_qt(node->src[1], ctx);
-                        if (qmm_op_supported(QMM_OP_MUL_MAT_F, &a, &b, nullptr, &d)) {
-                            if (qmm_op_compute(ctx->dev->qmm, QMM_OP_MUL_MAT_F, &a, &b, nullptr, &d, qmm_stream(ctx->dev->qmm))) {
-                                GGML_LOG_ERROR("MI355X MUL_MAT(%s) into merged heads: %s\n", node->name, qmm_last_error());
-                                return GGML_STATUS_FAILED;
-                            }
-                            done[jc] = 1;
-                            continue;
-                        }
-                    }
-                }
-            }
-            if (node->op == GGML_OP_MUL && node->src[1]->ne[0] == 1 && node->ne[1] >= 2 && node->ne[1] == node->src[1]->ne[1] && node->ne[3] == 1 &&
-                !GGML_MI355X_FUSE_OFF()) {
-                // experts * weights and the sum over the used experts through 2-D views (build_moe_ffn's tail): one launch
-                const int U = (int) node->ne[1];
-                const auto * rm = info(node);
-                int idx[64], k = 0;
-                for (int j = i + 1; j < n_nodes && j <= i + 4 * U + 4 && k < U - 1; ++j) {
-                    const ggml_tensor * t = cgraph->nodes[j];
-                    if (done[j] || is_noop(t)) continue;
-                    if (t->op != GGML_OP_ADD) break;
-                    idx[k++] = j;
-                }
-                const auto root = [](const ggml_tensor * t) { return t->view_src ? t->view_src : t; };
-                const auto is_slice = [&](const ggml_tensor * v, int u) {           // view_2d(experts, E, N, nb[2], u * nb[1])
-                    return root(v) == node && v->ne[0] == node->ne[0] && v->ne[1] == node->ne[2] && v->ne[2] == 1 && v->nb[1] == node->nb[2] &&
-                           (const char *) v->data == (const char *) node->data + (size_t) u * node->nb[1];
-                };
-                bool ok = k == U - 1 && rm && rm->uses == U && U <= 64 && !(node->flags & GGML_TENSOR_FLAG_OUTPUT);
-                for (int a = 0; ok && a < U - 1; ++a) {
-                    const ggml_tensor * ad = cgraph->nodes[idx[a]];
-                    ok = is_slice(ad->src[1], a + 1) && (a == 0 ? is_slice(ad->src[0], 0) : ad->src[0] == cgraph->nodes[idx[a - 1]]) &&
-                         (a == U - 2 || (single_use(ad) && !(ad->flags & GGML_TENSOR_FLAG_OUTPUT)));
-                }
-                if (ok) {
-                    const ggml_tensor * last = cgraph->nodes[idx[U - 2]];
-                    const qmm_tensor x = to_qt(node->src[0], ctx), w = to_qt(node->src[1], ctx), o = to_qt(last, ctx);
-                    if (qmm_moe_combine_supported(&x, &w, &o)) {
-                        if (qmm_moe_combine(ctx->dev->qmm, &x, &w, &o, qmm_stream(ctx->dev->qmm))) {
-                            GGML_LOG_ERROR("MI355X MoE combine(%s): %s\n", node->name, qmm_last_error());
-                            return GGML_STATUS_FAILED;
-                        }
-                        for (int a = 0; a < U - 1; ++a) done[idx[a]] = 1;
-                        continue;
-                    }
-                }
-            }
-            if (node->op == GGML_OP_SOFT_MAX && !node->src[1] && node->ne[0] <= 64 && node->ne[2] == 1 && node->ne[3] == 1 && !GGML_MI355X_FUSE_OFF()) {
-                // the MoE router behind its logits (build_moe_ffn): soft_max -> argsort (top_k view) -> get_rows -> sum_rows -> div
-                float scale, max_bias;
-                memcpy(&scale, (const float *) node->op_params + 0, sizeof(float));
-                memcpy(&max_bias, (const float *) node->op_params + 1, sizeof(float));
-                // llama.cpp's graph order puts get_rows / sum_rows / div (the weights, needed only by the final mul) BEHIND the expert
-                // MUL_MAT_IDs: the argsort follows the soft_max directly, the other three are looked for further down and run here,
-                // early (their inputs exist; where the div's buffer is still in use at this point the weights go to the scratch)
-                const auto root = [](const ggml_tensor * t) { return t->view_src ? t->view_src : t; };
-                int idx[4], k = 0;
-                std::vector<const ggml_tensor *> & skipped = ctx->skipped;
-                skipped.clear();
-                for (int j = i + 1; j < n_nodes && j <= i + 64 && k < 4; ++j) {
-                    const ggml_tensor * t = cgraph->nodes[j];
-                    if (done[j] || is_noop(t)) continue;
-                    const bool want = (k == 0 && t->op == GGML_OP_ARGSORT && t->src[0] == node) ||
-                                      (k == 1 && t->op == GGML_OP_GET_ROWS && root(t->src[0]) == node && root(t->src[1]) == cgraph->nodes[idx[0]]) ||
-                                      (k == 2 && t->op == GGML_OP_SUM_ROWS && root(t->src[0]) == cgraph->nodes[idx[1]]) ||
-                                      (k == 3 && t->op == GGML_OP_DIV && root(t->src[0]) == cgraph->nodes[idx[1]] && t->src[1] == cgraph->nodes[idx[2]]);
-                    if (want) idx[k++] = j;
-                    else if (k == 0) break;                                             // the argsort must come first
-                    else skipped.push_back(t);
-                }
-                if (k == 4 && scale == 1.0f && max_bias == 0.0f) {
-                    ggml_tensor * as = cgraph->nodes[idx[0]], * gr = cgraph->nodes[idx[1]], * sr = cgraph->nodes[idx[2]], * dv = cgraph->nodes[idx[3]];
-                    const auto * ri = info(node), * rg = info(gr), * rs = info(sr);
-                    if (as->op == GGML_OP_ARGSORT && as->src[0] == node && as->op_params[0] == GGML_SORT_ORDER_DESC &&
-                        gr->op == GGML_OP_GET_ROWS && root(gr->src[0]) == node && gr->src[0]->ne[0] == 1 && root(gr->src[1]) == as &&
-                        gr->src[1]->data == as->data && gr->src[1]->nb[1] == as->nb[1] && gr->src[1]->ne[1] == as->ne[1] &&
-                        sr->op == GGML_OP_SUM_ROWS && root(sr->src[0]) == gr && dv->op == GGML_OP_DIV && root(dv->src[0]) == gr && dv->src[1] == sr &&
-                        ri && ri->uses == 2 && rg && rg->uses == 2 && rs && rs->uses == 1 && ggml_is_contiguous(dv) && ggml_is_contiguous(gr) &&
-                        !(node->flags & GGML_TENSOR_FLAG_OUTPUT) && !(gr->flags & GGML_TENSOR_FLAG_OUTPUT) && !(sr->flags & GGML_TENSOR_FLAG_OUTPUT)) {
-                        const int64_t n_used = gr->src[1]->ne[0];
-                        // the weights are written now, not at the div's place in the graph: its block must be free here
-                        if (!can_hoist(dv, skipped) && !hoist_elsewhere(ctx, dv)) goto router_done;
-                        const qmm_tensor lg = to_qt(node->src[0], ctx), ids = to_qt(as, ctx), w = to_qt(dv, ctx);
-                        if (qmm_moe_router_supported(&lg, &ids, &w, n_used)) {
-                            if (qmm_moe_router(ctx->dev->qmm, &lg, &ids, &w, n_used, 1, qmm_stream(ctx->dev->qmm))) {
-                                GGML_LOG_ERROR("MI355X MoE router(%s): %s\n", node->name, qmm_last_error());
-                                return GGML_STATUS_FAILED;
-                            }
-                            if (dbg()) fprintf(stderr, "fused: moe router (%s)\n", node->name);
-                            for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
-                            continue;
-                        }
-                    }
-                }
-                router_done:;
-            }
-            if (node->op == GGML_OP_ROPE && !GGML_MI355X_FUSE_OFF()) {
-                // rope(q) with, from further down the graph, rope(k) -> K cache and v -> V cache (build_attn's two ggml_cpy): one launch
-                // (any batch size: at 512 tokens 29 us of four launches become one, pp512 31.2k -> 32.0k).
-                // Their inputs must exist already (k and v were hoisted into the q/k/v group); the cache is not compute-buffer
-                // memory, so storing early cannot collide with anything in between.
-                auto ready = [&](const ggml_tensor * t) {                            // was t's root produced before this point?
-                    const ggml_tensor * root = t->view_src ? t->view_src : t;
-                    for (int j = i + 1; j < n_nodes && j <= i + 2 * LOOKAHEAD; ++j)
-                        if (cgraph->nodes[j] == root) return done[j] != 0;
-                    return true;
-                };
-                int jk = -1, jck = -1, jcv = -1;
-                for (int j = i + 1; j < n_nodes && j <= i + 2 * LOOKAHEAD; ++j) {
-                    const ggml_tensor * t = cgraph->nodes[j];
-                    if (done[j] || is_noop(t)) continue;
-                    if (jk < 0 && t->op == GGML_OP_ROPE && t->src[1] == node->src[1] && t->src[2] == node->src[2] && t->ne[0] == node->ne[0] &&
-                        !memcmp(t->op_params, node->op_params, sizeof(t->op_params)) && t->type == GGML_TYPE_F32 && ggml_is_contiguous(t) &&
-                        single_use(t) && ready(t->src[0])) {
-                        jk = j;
-                    } else if (jk >= 0 && jck < 0 && t->op == GGML_OP_CPY && t->src[0] == cgraph->nodes[jk] && t->type == GGML_TYPE_F16 && ggml_is_contiguous(t)) {
-                        jck = j;
-                    } else if (jcv < 0 && t->op == GGML_OP_CPY && t->type == GGML_TYPE_F16 && t->src[0]->type == GGML_TYPE_F32 &&
-                               (t->src[0]->view_src ? t->src[0]->view_src : t->src[0])->op == GGML_OP_MUL_MAT && ready(t->src[0]) &&
-                               (jk < 0 || t->src[0] != cgraph->nodes[jk])) {
-                        jcv = j;
-                    } else if (t->op == GGML_OP_MUL_MAT || t->op == GGML_OP_SOFT_MAX) {
-                        break;                                                         // attention starts: nothing to find beyond
-                    }
-                }
-                if (jk >= 0 && jck < 0) jk = -1;                                       // rope(k) without its store stays where it is
-                if (jk >= 0 || jcv >= 0) {
-                    const qmm_tensor q = to_qt(node->src[0], ctx), pos = to_qt(node->src[1], ctx), qd = to_qt(node, ctx);
-                    qmm_tensor ff{}, k{}, kd{}, v{}, vd{};
-                    if (node->src[2]) ff = to_qt(node->src[2], ctx);
-                    if (jk >= 0) {
-                        const ggml_tensor * rk = cgraph->nodes[jk];
-                        k = to_qt(rk->src[0], ctx);
-                        kd = to_qt(rk, ctx);                                           // shape of rope(k), bytes of the cache view
-                        kd.data = cgraph->nodes[jck]->data;
-                        kd.type = GGML_TYPE_F16;
-                        kd.nb[0] = 2;
-                        for (int a = 1; a < 4; ++a) kd.nb[a] = kd.nb[a - 1] * kd.ne[a - 1];
-                    }
-                    if (jcv >= 0) {
-                        v = to_qt(cgraph->nodes[jcv]->src[0], ctx);
-                        vd = to_qt(cgraph->nodes[jcv], ctx);
-                    }
-                    const qmm_tensor * pff = node->src[2] ? &ff : nullptr, * pk = jk >= 0 ? &k : nullptr, * pkd = jk >= 0 ? &kd : nullptr,
-                                     * pv = jcv >= 0 ? &v : nullptr, * pvd = jcv >= 0 ? &vd : nullptr;
-                    // ... and when the attention chain follows (few tokens): rope, KV store and attention in one launch
-                    // (GGML_MI355X_ATTN_ROPE=0: two launches; tg128 395 -> 403 tok/s)
-                    if (jk >= 0 && jcv >= 0 && node->ne[2] <= 8 && single_use(node) && GGML_MI355X_ATTN_ROPE()) {
-                        int idx[5], kq_n = 0;
-                        for (int j = std::max(jck, jcv) + 1; j < n_nodes && j <= i + 4 * LOOKAHEAD && kq_n < 5; ++j) {
-                            const ggml_tensor * t = cgraph->nodes[j];
-                            if (done[j] || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_TRANSPOSE) continue;
-                            if (kq_n == 0 && t->op == GGML_OP_PERMUTE) continue;                   // q's permute in front of kq
-                            idx[kq_n++] = j;
-                        }
-                        if (kq_n == 5) {
-                            ggml_tensor * kqn = cgraph->nodes[idx[0]], * sm = cgraph->nodes[idx[1]], * kqv = cgraph->nodes[idx[2]], * pm = cgraph->nodes[idx[3]],
-                                        * ct = cgraph->nodes[idx[4]];
-                            float scale, max_bias;
-                            memcpy(&scale, (const float *) sm->op_params + 0, sizeof(float));
-                            memcpy(&max_bias, (const float *) sm->op_params + 1, sizeof(float));
-                            if (kqn->op == GGML_OP_MUL_MAT && kqn->src[0]->type == GGML_TYPE_F16 && kqn->src[1]->op == GGML_OP_PERMUTE &&
-                                kqn->src[1]->src[0] == node && single_use(kqn) && sm->op == GGML_OP_SOFT_MAX && sm->src[0] == kqn && sm->src[1] &&
-                                max_bias == 0.0f && single_use(sm) && kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm &&
-                                kqv->src[0]->type == GGML_TYPE_F16 && single_use(kqv) && pm->op == GGML_OP_PERMUTE && pm->src[0] == kqv &&
-                                pm->ne[0] == kqv->ne[0] && pm->ne[1] == kqv->ne[2] && pm->ne[2] == kqv->ne[1] && ct->op == GGML_OP_CONT && ct->src[0] == pm &&
-                                ((early_write_ok(ct, { node->src[1], node->src[2], cgraph->nodes[jk]->src[0], cgraph->nodes[jcv]->src[0],
-                                                       kqn->src[0], kqv->src[0], sm->src[1] }) &&
-                                  early_write_ok(ct, { node->src[0] }, node->src[0], true) && early_write_ok(ct, { node }, node, true)) ||
-                                 hoist_elsewhere(ctx, ct))) {
-                                const qmm_tensor kc = to_qt(kqn->src[0], ctx), vc = to_qt(kqv->src[0], ctx), m = to_qt(sm->src[1], ctx), d = to_qt(ct, ctx);
-                                const int64_t off = (const char *) kd.data - (const char *) kc.data;
-                                const int64_t j0 = kc.nb[1] > 0 && off >= 0 && off % kc.nb[1] == 0 ? off / kc.nb[1] : -1;
-                                const bool v_ok = (const char *) vd.data - (const char *) vc.data == j0 * 2;
-                                if (j0 >= 0 && v_ok && qmm_attn_decode_rope_supported(&q, &pos, pff, &qd, &k, &kd, &v, &vd, &kc, &vc, &m, &d, j0)) {
-                                    if (qmm_attn_decode_rope(ctx->dev->qmm, &q, &pos, pff, &qd, &k, &kd, &v, &vd, &kc, &vc, &m, &d, scale, j0,
-                                                             qmm_stream(ctx->dev->qmm))) {
-                                        GGML_LOG_ERROR("MI355X rope + KV store + attention(%s): %s\n", node->name, qmm_last_error());
-                                        return GGML_STATUS_FAILED;
-                                    }
-                                    if (dbg()) fprintf(stderr, "fused: rope + kv store + attention (%s)\n", node->name);
-                                    done[jk] = done[jck] = done[jcv] = 1;
-                                    for (int j = 0; j < 5; ++j) done[idx[j]] = 1;
-                                    continue;
-                                }
-                            }
-                        }
-                    }
-                    if (qmm_rope_kv_store_supported(&q, &pos, pff, &qd, pk, pkd, pv, pvd)) {
-                        if (qmm_rope_kv_store(ctx->dev->qmm, &q, &pos, pff, &qd, pk, pkd, pv, pvd, qmm_stream(ctx->dev->qmm))) {
-                            GGML_LOG_ERROR("MI355X rope + KV store(%s): %s\n", node->name, qmm_last_error());
-                            return GGML_STATUS_FAILED;
-                        }
-                        if (jk >= 0) done[jk] = done[jck] = 1;
-                        if (jcv >= 0) done[jcv] = 1;
-                        continue;
-                    }
-                }
-            }
-            if (i + 1 < n_nodes && node->op == GGML_OP_RMS_NORM && single_use(node)) fop = fused_pair(node, cgraph->nodes[i + 1], &other);
+            int r = 0;
+            if (deferred[i]) r = P.site_deferred_silu_mul(i, node, gop);
+            if (r == 0) r = P.site_hold_silu(i, node, gop);
+            if (r == 0) r = P.site_add_rms_norm(i, node, gop);
+            if (r == 0) r = P.site_attention(i, node, gop);
+            if (r == 0) r = P.site_kqv_into_merged_heads(i, node, gop);
+            if (r == 0) r = P.site_moe_combine(i, node, gop);
+            if (r == 0) r = P.site_moe_router(i, node, gop);
+            if (r == 0) r = P.site_rope_kv_attention(i, node, gop);
+            if (r < 0) return GGML_STATUS_FAILED;
+            if (r > 0) continue;
+            if (i + 1 < n_nodes && node->op == GGML_OP_RMS_NORM && P.single_use(node)) fop = fused_pair(node, cgraph->nodes[i + 1], &other);
             if (fop == QMM_OP_RMS_NORM_MUL && node->ne[1] <= QMM_MATVEC_MAX_N && node->ne[2] == 1 && node->ne[3] == 1 && !GGML_MI355X_FUSE_OFF()) {
                 // every reader of the normed row a quantized MUL_MAT of one group (q/k/v, gate/up, output)?  Then no launch here:
                 // compute_mul_mat hands the norm to the mat-vec kernels, or materializes it if the group turns out smaller
                 const ggml_tensor * mul = cgraph->nodes[i + 1];
-                const auto * ri = info(mul);
+                const auto * ri = P.info(mul);
                 const ggml_tensor * x = node->src[0];
                 int found = 0, first = -1;
                 for (int j = i + 2; j < n_nodes && j <= i + 2 + LOOKAHEAD && ri; ++j) {
