@@ -566,42 +566,91 @@ fail:
     return GGML_STATUS_FAILED;
 }
 
-enum ggml_status compute_mul_mat_split(mi355x_backend_ctx * ctx, const ggml_tensor * dst) {
-    const ggml_tensor * a = dst->src[0], * b = dst->src[1];
-    auto * e = (const split_extra *) a->extra;
+// Round 2: the MUL_MATs of a group (same src1: wq / wk / wv, ffn_gate / ffn_up) go out together: every other device gets src1 ONCE,
+// computes its slice of each matrix, sends the slices back, and there is one event round trip per device and group instead of one per
+// matrix (`members`: found by compute_mul_mat_split_group with the unsplit path's hoisting rules).
+qmm_tensor to_qt(const ggml_tensor * t, const mi355x_backend_ctx * ctx);
+enum ggml_status compute_mul_mat_split(mi355x_backend_ctx * ctx, const ggml_tensor * const * members, int n_members) {
+    const ggml_tensor * dst = members[0];
+    const ggml_tensor * b = dst->src[1];
     mi355x_device_ctx * root = ctx->dev;
     void * rst = qmm_stream(root->qmm);
-    const int64_t K = a->ne[0], N = b->ne[1], ldx = b->nb[1] / sizeof(float), ldd = dst->nb[1] / sizeof(float);
-    if (ldx == K)                                             // (RCCL moves whole buffers: a strided src1 keeps the 2-D peer copies)
+    const int64_t K = dst->src[0]->ne[0], N = b->ne[1], ldx = b->nb[1] / sizeof(float);
+    if (ldx == K && n_members == 1)                           // (RCCL moves whole buffers: a strided src1 keeps the 2-D peer copies)
         if (qmm_comm * comm = split_comm()) return compute_mul_mat_split_rccl(ctx, dst, comm);
     if (!root->ev_ready) root->ev_ready = qmm_event_create(root->qmm);
     if (!root->ev_ready || qmm_event_record(root->qmm, root->ev_ready, rst)) goto fail;
     for (int id = 0; id < g_ndev; ++id) {
-        const int64_t rows = e->hi[id] - e->lo[id];
-        if (rows == 0) continue;
         mi355x_device_ctx * d = &g_devs[id];
+        size_t slice_floats = 0;
+        for (int m = 0; m < n_members; ++m) {
+            auto * e = (const split_extra *) members[m]->src[0]->extra;
+            slice_floats += (size_t) N * (e->hi[id] - e->lo[id]);
+        }
+        if (slice_floats == 0) continue;
         if (d == root) {
-            if (qmm_mul_mat(root->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) b->data, N, ldx,
-                            (float *) dst->data + e->lo[id], ldd, rst)) goto fail;
+            for (int m = 0; m < n_members; ++m) {
+                const ggml_tensor * a = members[m]->src[0];
+                auto * e = (const split_extra *) a->extra;
+                const int64_t rows = e->hi[id] - e->lo[id];
+                if (rows && qmm_mul_mat(root->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) b->data, N, ldx,
+                                        (float *) to_qt(members[m], ctx).data + e->lo[id], members[m]->nb[1] / sizeof(float), rst)) goto fail;
+            }
             continue;
         }
         void * st = qmm_stream(d->qmm);
         if (!d->ev_done) d->ev_done = qmm_event_create(d->qmm);
         if (!d->ev_done || !grow(d, d->stage_x, d->stage_x_bytes, (size_t) N * K * sizeof(float)) ||
-            !grow(d, d->stage_d, d->stage_d_bytes, (size_t) N * rows * sizeof(float))) goto fail;
+            !grow(d, d->stage_d, d->stage_d_bytes, slice_floats * sizeof(float))) goto fail;
         if (qmm_stream_wait_event(d->qmm, st, root->ev_ready) ||
-            qmm_memcpy2d_d2d(d->qmm, d->stage_x, K * sizeof(float), b->data, b->nb[1], K * sizeof(float), N, st) ||
-            qmm_mul_mat(d->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) d->stage_x, N, K,
-                        (float *) d->stage_d, rows, st) ||
-            qmm_memcpy2d_d2d(d->qmm, (float *) dst->data + e->lo[id], dst->nb[1], d->stage_d, rows * sizeof(float),
-                             rows * sizeof(float), N, st) ||
-            qmm_event_record(d->qmm, d->ev_done, st) ||
-            qmm_stream_wait_event(root->qmm, rst, d->ev_done)) goto fail;
+            qmm_memcpy2d_d2d(d->qmm, d->stage_x, K * sizeof(float), b->data, b->nb[1], K * sizeof(float), N, st)) goto fail;
+        {
+            size_t off = 0;
+            for (int m = 0; m < n_members; ++m) {
+                const ggml_tensor * a = members[m]->src[0];
+                auto * e = (const split_extra *) a->extra;
+                const int64_t rows = e->hi[id] - e->lo[id];
+                if (rows == 0) continue;
+                float * part = (float *) d->stage_d + off;
+                if (qmm_mul_mat(d->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) d->stage_x, N, K, part, rows, st) ||
+                    qmm_memcpy2d_d2d(d->qmm, (float *) to_qt(members[m], ctx).data + e->lo[id], members[m]->nb[1], part, rows * sizeof(float),
+                                     rows * sizeof(float), N, st)) goto fail;
+                off += (size_t) N * rows;
+            }
+        }
+        if (qmm_event_record(d->qmm, d->ev_done, st) || qmm_stream_wait_event(root->qmm, rst, d->ev_done)) goto fail;
     }
     return GGML_STATUS_SUCCESS;
 fail:
     GGML_LOG_ERROR("MI355X MUL_MAT(%s) row split: %s\n", dst->name, qmm_last_error());
     return GGML_STATUS_FAILED;
+}
+
+bool dbg();
+void * hoist_elsewhere(mi355x_backend_ctx * ctx, const ggml_tensor * d);
+bool is_noop(const ggml_tensor * node);
+bool can_hoist(const ggml_tensor * t, const std::vector<const ggml_tensor *> & skipped);
+bool supports_mul_mat(const struct ggml_tensor * op);
+// nodes[0] is a MUL_MAT on row-split weights: later MUL_MATs on the same src1 with split weights join it where they may run early
+enum ggml_status compute_mul_mat_split_group(mi355x_backend_ctx * ctx, ggml_tensor * const * nodes, int n_nodes, char * done) {
+    const ggml_tensor * members[4] = { nodes[0], nullptr, nullptr, nullptr };
+    int n = 1;
+    const ggml_tensor * b = nodes[0]->src[1];
+    std::vector<const ggml_tensor *> & skipped = ctx->skipped;
+    skipped.clear();
+    for (int i = 1; i < n_nodes && i <= 12 && n < 4 && !GGML_MI355X_FUSE_OFF(); ++i) {
+        const ggml_tensor * d = nodes[i];
+        if (done[i] || is_noop(d)) continue;
+        if (d->op == GGML_OP_MUL_MAT && d->src[1] == b && is_split(d->src[0]) && supports_mul_mat(d) && d->src[0]->ne[0] == nodes[0]->src[0]->ne[0] &&
+            (can_hoist(d, skipped) || hoist_elsewhere(ctx, d))) {          // (its block still in use here: into the scratch, readers redirected)
+            members[n++] = d;
+            done[i] = 1;
+            continue;
+        }
+        skipped.push_back(d);
+    }
+    if (dbg()) fprintf(stderr, "split group of %d at %s (N=%lld)\n", n, nodes[0]->name, (long long) b->ne[1]);
+    return compute_mul_mat_split(ctx, members, n);
 }
 
 int glue_op(const ggml_tensor * node);
@@ -700,7 +749,7 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
     const ggml_tensor * a = dst->src[0], * b = dst->src[1];
     qmm_ctx * q = ctx->dev->qmm;
     void * st = qmm_stream(q);
-    if (is_split(a)) return compute_mul_mat_split(ctx, dst);
+    if (is_split(a)) return compute_mul_mat_split_group(ctx, nodes, n_nodes, done);
     const int64_t K = a->ne[0], N = b->ne[1];
     const bool flat = a->ne[2] == 1 && a->ne[3] == 1 && b->ne[2] == 1 && b->ne[3] == 1;
     if (flat) {
