@@ -33,48 +33,34 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def launch_class(grp):
+    """which launch of a layer a group is: the classes VERDICT r2 asked to see separately"""
+    n = grp.mats[0].name.split(".")[-1]
+    return {"attn_q": "qkv", "attn_output": "wo", "ffn_gate": "gate_up", "ffn_down": "down", "ffn_gate_exps": "gate_up_exps",
+            "ffn_down_exps": "down_exps", "output": "output"}.get(n, n)
+
+
 def roofline_leg(hp, q, n_batch, torch, n_outputs=None):
-    """HIP-event timing of the pass's launches, bucketed by kernel.  The model's 32 layers give every launch shape 16-32
-    distinct weight sets, so each bucket is issued back to back on rotating weights (no Infinity-Cache reuse) inside ONE
-    event pair on the launch stream, behind a spin kernel that keeps the host ahead of the GPU.  Average launch duration
-    = bucket time / launches (it includes the kernel-to-kernel boundary, not a per-launch event cost)."""
+    """HIP-event timing of the pass's launches.  Every group is issued through HotPath.group_call, i.e. by the very closure the timed
+    pass runs, and is bucketed by (launch class, the kernels that call issued): the labels come from the library's own launch
+    sites (qmm_trace_begin / qmm_trace_end), not from a replica of its dispatch rules.  The model's 32 layers give every bucket
+    16-32 distinct weight sets, so a bucket is issued back to back on rotating weights (no Infinity-Cache reuse) inside ONE event
+    pair on the launch stream, behind a spin kernel that keeps the host ahead of the GPU.  Bucket time / launches = average
+    launch duration including the kernel-to-kernel boundary (not a per-launch event cost).
+    Returns {(class, labels): [algorithmic bytes, flops, seconds, calls]}."""
     buckets = {}
     for grp in hp.wl.groups:
         n_tokens = hp.wl.group_tokens(grp, n_batch, n_outputs)          # the groups computed on the output rows only run at n_outputs
-        x, dst_local, _, ids = hp.prepare(n_tokens)
+        fn = hp.group_call(grp, hp.prepare(n_tokens))
+        labels = q.trace(fn)                                            # (also the warm-up call of this weight set)
         m0 = grp.mats[0]
-        if m0.n_expert:
-            ne11 = m0.n_used if m0.name.endswith("down_exps") else 1
-            ws = [hp.weights[m.name][0] for m in grp.mats]
-            outs = [dst_local[("id", m.name.split(".")[-1], m.M)] for m in grp.mats]
-            if len(grp.mats) == 2 and grp.mats[1].type == m0.type:
-                fn = (lambda m0=m0, ws=ws, outs=outs, ne11=ne11, x=x, ids=ids:
-                      q.mul_mat_id_pair(hp.types[m0.name], ws[0], ws[1], m0.K, x[(m0.K, ne11)], ids[:, :m0.n_used], outs[0], outs[1]))
-                buckets.setdefault(("id", m0.type, n_tokens > 8), []).append(
-                    (fn, sum(m.algo_bytes(n_tokens) for m in grp.mats) - n_tokens * m0.K * 4, sum(m.flops(n_tokens) for m in grp.mats)))
-            else:
-                for m, w, o in zip(grp.mats, ws, outs):
-                    fn = (lambda m=m, w=w, o=o, ne11=ne11, x=x, ids=ids: q.mul_mat_id(hp.types[m.name], w, m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=o))
-                    buckets.setdefault(("id", m.type, n_tokens > 8), []).append((fn, m.algo_bytes(n_tokens), m.flops(n_tokens)))
-            continue
-        # one launch per run of same-type weights inside the group (that is how qmm_mul_mat_group issues them)
-        i = 0
-        while i < len(grp.mats):
-            j = i
-            while j < len(grp.mats) and grp.mats[j].type == grp.mats[i].type:
-                j += 1
-            if n_tokens > 8:
-                j = i + 1
-            ws, outs, nbytes, fl = [], [], n_tokens * m0.K * 4, 0
-            for m in grp.mats[i:j]:
-                w, _ = hp.weights[m.name]
-                ws.append((hp.types[m.name], w))
-                outs.append(dst_local[(m.name.split(".")[-1], w.shape[0])])
-                nbytes += w.numel() + n_tokens * w.shape[0] * 4
-                fl += 2 * w.shape[0] * m.K * n_tokens
-            fn = (lambda ws=ws, outs=outs, K=m0.K, x=x: q.mul_mat_group(ws, K, x[K], outs))
-            buckets.setdefault(("mm", grp.mats[i].type, n_tokens > 8), []).append((fn, nbytes, fl))
-            i = j
+        nbytes = sum(m.algo_bytes(n_tokens) for m in grp.mats) - (len(grp.mats) - 1) * n_tokens * m0.K * 4 * (1 if not m0.n_expert else 0)
+        if m0.n_expert and len(grp.mats) == 2:
+            nbytes -= n_tokens * m0.K * 4                               # the twin MUL_MAT_IDs share src1 as well
+        if hp.world > 1:                                                # this rank's shard: weights and dst columns are split, src1 is not
+            nbytes = n_tokens * m0.K * 4 + sum(hp.weights[m.name][0].numel() + n_tokens * hp.weights[m.name][0].shape[0] * 4 for m in grp.mats)
+        fl = sum(m.flops(n_tokens) for m in grp.mats) // hp.world
+        buckets.setdefault((launch_class(grp), labels), []).append((fn, nbytes, fl))
     torch.cuda.synchronize()
     torch.cuda._sleep(int(2.0e8))
     evs = {}
@@ -91,6 +77,16 @@ def roofline_leg(hp, q, n_batch, torch, n_outputs=None):
         e0, e1 = evs[key]
         agg[key] = [sum(i[1] for i in items), sum(i[2] for i in items), e0.elapsed_time(e1) * 1e-3, len(items)]
     return agg
+
+
+def by_kernel(agg):
+    """token generation: one group is one launch, so a bucket's label IS its kernel; merge the classes that ran the same one"""
+    out = {}
+    for (cls, labels), (nb, fl, sec, cnt) in agg.items():
+        k = " + ".join(labels)
+        a = out.setdefault(k, [0, 0, 0.0, 0, 0, []])
+        a[0] += nb; a[1] += fl; a[2] += sec; a[3] += cnt; a[4] += cnt * len(labels); a[5].append(cls)
+    return out
 
 
 class LlamaBench:
@@ -282,7 +278,6 @@ def main():
     from ggml_hexagon_amd.capi import Qmm
     from ggml_hexagon_amd.hotpath import HotPath
     from ggml_hexagon_amd.rowsplit import RowConcat
-    from ggml_hexagon_amd.synth import NAMES
 
     q = Qmm(local)
     wl = workload.get(args.workload)
@@ -357,35 +352,53 @@ def main():
     agg1 = roofline_leg(hp, q, 1, torch)
     aggp = roofline_leg(hp, q, args.n_prompt, torch, n_out_pp)
 
-    def dominant(agg, batched=None):
-        keys = [k for k in agg if batched is None or k[2] == batched]
-        key = max(keys, key=lambda k: agg[k][2])
-        nb, fl, sec, cnt = agg[key]
-        return key, nb, fl, sec, cnt
-
-    k1, nb1, fl1, s1, c1 = dominant(agg1)
-    kp, nbp, flp, sp, cp = dominant(aggp, batched=True)
-    kernel1 = f"qmm::matvec_kernel<{NAMES.get(k1[1], k1[1])},1>" if k1[0] == "mm" else f"qmm::matvec_id_kernel<{NAMES.get(k1[1])}>"
-    traffic = None
+    # token generation: per kernel (a one-token group is ONE launch; buckets of different launch classes that ran the same kernel merge)
+    kern1 = by_kernel(agg1)
+    k1 = max(kern1, key=lambda k: kern1[k][2])
+    nb1, _, s1, calls1, launches1, classes1 = kern1[k1]
+    traffic, traffic_note = None, None
     tf = ROOT / "profiles" / "pmc_traffic.json"
     if tf.exists():
-        # HBM bytes per launch from the PMC passes (profiles/README.md): only when that file was measured on THIS kernel
-        # (its name, template arguments included, as rocprofv3 prints it) and this workload
+        # HBM bytes per launch from the PMC passes (profiles/tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes over THIS
+        # leg's dispatch population, gfx950 corrections applied): taken only from a file that names this kernel and this workload
         try:
             tj = json.loads(tf.read_text())
-            want = f"matvec_kernel<{k1[1]}, 1, false>" if k1[0] == "mm" else None
-            if want and want in tj.get("kernel", "") and tj.get("workload") == wl.name:
-                traffic = tj.get("matvec_bytes_per_launch")
+            if tj.get("label") == k1 and tj.get("workload") == wl.name:
+                traffic = tj.get("bytes_per_launch")
+                traffic_note = {"algo_bytes_per_launch_of_that_population": tj.get("algo_bytes_per_launch"), "ratio": tj.get("ratio"), "dispatches": tj.get("dispatches")}
         except Exception:
             traffic = None
-    roof = {"bound": "hbm", "kernel": kernel1,
+    roof = {"bound": "hbm", "kernel": "qmm::" + k1,
             "achieved": round(nb1 / s1 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb1 / s1 / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "launches": c1, "avg_launch_us": round(s1 / c1 * 1e6, 2), "algo_bytes_per_launch": int(nb1 / c1),
-            "all_tg_launches_GBs": round(sum(a[0] for a in agg1.values()) / sum(a[2] for a in agg1.values()) / 1e9, 1)}
-    pp_kernel = ("qmm::mfma_r64_q4k_kernel<8> | mfma_regb_q4k_kernel<8,128>" if NAMES.get(kp[1]) == "q4_K" else f"qmm::mfma_regb_kernel<{NAMES.get(kp[1], kp[1])}>")
-    roof_pp = {"bound": "mfma", "kernel": pp_kernel + " (+prep_act)",
+            "traffic": traffic, "traffic_population": traffic_note, "launches": launches1, "launch_classes": sorted(set(classes1)),
+            "avg_launch_us": round(s1 / launches1 * 1e6, 2), "algo_bytes_per_launch": int(nb1 / launches1),
+            "all_tg_launches_GBs": round(sum(a[0] for a in agg1.values()) / sum(a[2] for a in agg1.values()) / 1e9, 1),
+            "kernels": {k: {"launches": v[4], "avg_launch_us": round(v[2] / v[4] * 1e6, 2), "GBs": round(v[0] / v[2] / 1e9, 1),
+                            "frac": round(v[0] / v[2] / 1e9 / HBM_PEAK_GBS, 4), "classes": sorted(set(v[5]))} for k, v in kern1.items()}}
+    # prompt pass: per launch class (qkv / wo / gate_up / down), each INCLUDING its prep_act and splitk_reduce launches; the groups
+    # llama-bench's prompt pass runs on one row (last layer's FFN, output projection) are mat-vec launches and listed apart
+    cls_pp = {}
+    for (cls, labels), (nb, fl, sec, cnt) in aggp.items():
+        batched = any(l.startswith(("mfma_", "prep_act")) for l in labels)
+        c = cls_pp.setdefault((cls, batched), {"flops": 0, "s": 0.0, "calls": 0, "launches": 0, "kernels": set()})
+        c["flops"] += fl; c["s"] += sec; c["calls"] += cnt; c["launches"] += cnt * len(labels); c["kernels"].update(labels)
+    pp_classes = {}
+    for (cls, batched), c in cls_pp.items():
+        if not batched:
+            continue
+        pp_classes[cls] = {"TFLOPs": round(c["flops"] / c["s"] / 1e12, 1), "frac": round(c["flops"] / c["s"] / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                           "us_per_call": round(c["s"] / c["calls"] * 1e6, 2), "calls": c["calls"], "launches_per_call": round(c["launches"] / c["calls"], 2),
+                           "share_of_pp_time": None, "kernels": sorted(c["kernels"])}
+    tot_pp_s = sum(c["s"] for (cls, batched), c in cls_pp.items())
+    for (cls, batched), c in cls_pp.items():
+        if batched:
+            pp_classes[cls]["share_of_pp_time"] = round(c["s"] / tot_pp_s, 4)
+    bat = [(k, c) for k, c in cls_pp.items() if k[1]]
+    flp, sp = sum(c["flops"] for _, c in bat), sum(c["s"] for _, c in bat)
+    (kp, _), cdom = max(bat, key=lambda kc: kc[1]["s"])
+    roof_pp = {"bound": "mfma", "kernel": "all batched launches of the prompt pass, each class with its prep_act / splitk_reduce launches",
                "achieved": round(flp / sp / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flp / sp / 1e12 / MFMA_PEAK_TFLOPS, 4),
-               "launches": cp, "avg_launch_us": round(sp / cp * 1e6, 2)}
+               "dominant_class": kp, "classes": pp_classes}
 
     out = {
         "metric": "llama-bench pp512 & tg128 tok/s over the offloaded quantized MUL_MAT/MUL_MAT_ID path (value = tg128)",

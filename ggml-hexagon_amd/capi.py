@@ -20,7 +20,7 @@ EXPORTS = [
     "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_event_create_timing", "qmm_event_elapsed_ms", "qmm_memcpy_h2d_async",
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_planar_type", "qmm_repack_rows", "qmm_dequantize",
     "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_swiglu_in", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
-    "qmm_chain_begin", "qmm_chain_flush", "qmm_chain_end", "qmm_chain_stats", "qmm_chain_debug",
+    "qmm_chain_begin", "qmm_chain_flush", "qmm_chain_end", "qmm_chain_stats", "qmm_chain_debug", "qmm_trace_begin", "qmm_trace_end",
     "qmm_comm_create", "qmm_comm_destroy", "qmm_comm_size", "qmm_comm_broadcast", "qmm_comm_gather", "qmm_comm_all_gather",
 ]
 # include/ggml_mi355x_ops.h: the glue ops of a transformer layer
@@ -127,6 +127,8 @@ def load_library() -> C.CDLL:
         f.argtypes = [v]
     lib.qmm_chain_stats.argtypes = [v, C.POINTER(i32), C.POINTER(i32)]
     lib.qmm_chain_debug.argtypes = [v, v]
+    lib.qmm_trace_begin.argtypes = [v]
+    lib.qmm_trace_end.argtypes = [v, C.c_char_p, sz]
     return lib
 
 
@@ -190,6 +192,18 @@ class Qmm:
         a, b = C.c_int(0), C.c_int(0)
         self._chk(self.lib.qmm_chain_stats(self.ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def trace(self, fn):
+        """the kernels `fn()` launches through this context, as a tuple of labels (qmm_trace_begin / qmm_trace_end)"""
+        self._chk(self.lib.qmm_trace_begin(self.ctx))
+        try:
+            fn()
+        finally:
+            buf = C.create_string_buffer(8192)
+            n = self.lib.qmm_trace_end(self.ctx, buf, len(buf))
+        if n < 0:
+            self._chk(n)
+        return tuple(x for x in buf.value.decode().split(";") if x)
 
     def planar_type(self, t, k, row_bytes):
         return self.lib.qmm_planar_type(t, k, row_bytes)

@@ -1377,6 +1377,10 @@ int graph_pass::site_moe_combine(int i, ggml_tensor * node, int gop) {
         }
         if (ok) {
             const ggml_tensor * last = cgraph->nodes[idx[U - 2]];
+            // the launch writes the LAST add's buffer at the MUL's position, while other workgroups still read the experts and the
+            // weights: ggml-alloc may have put it on either (both are dead at the add's place in the graph).  A token's U expert
+            // rows and its one output row are laid out differently, so not even the same address is in place
+            if (!early_write_ok(last, { node->src[0], node->src[1] }) && !hoist_elsewhere(ctx, last)) return 0;
             const qmm_tensor x = to_qt(node->src[0], ctx), w = to_qt(node->src[1], ctx), o = to_qt(last, ctx);
             if (qmm_moe_combine_supported(&x, &w, &o)) {
                 if (qmm_moe_combine(ctx->dev->qmm, &x, &w, &o, qmm_stream(ctx->dev->qmm))) {
@@ -1427,8 +1431,12 @@ int graph_pass::site_moe_router(int i, ggml_tensor * node, int gop) {
                 ri && ri->uses == 2 && rg && rg->uses == 2 && rs && rs->uses == 1 && ggml_is_contiguous(dv) && ggml_is_contiguous(gr) &&
                 !(node->flags & GGML_TENSOR_FLAG_OUTPUT) && !(gr->flags & GGML_TENSOR_FLAG_OUTPUT) && !(sr->flags & GGML_TENSOR_FLAG_OUTPUT)) {
                 const int64_t n_used = gr->src[1]->ne[0];
-                // the weights are written now, not at the div's place in the graph: its block must be free here
-                if (!can_hoist(dv, skipped) && !hoist_elsewhere(ctx, dv)) return 0;
+                // the ids are written while other waves (one per token) still read logits rows: in place only at the very same address
+                // with the same rows (a wave reads its row first).  The weights are written now, not at the div's place in the graph:
+                // their block must be free here AND clear of the logits: at the div's place the logits are dead, so a non-inplace
+                // dv may sit on them with rows of 4 * n_used bytes against 4 * n_expert; otherwise into the scratch
+                if (!early_write_ok(as, { node->src[0] }, node->src[0])) return 0;
+                if (!(can_hoist(dv, skipped) && early_write_ok(dv, { node->src[0], as })) && !hoist_elsewhere(ctx, dv)) return 0;
                 const qmm_tensor lg = to_qt(node->src[0], ctx), ids = to_qt(as, ctx), w = to_qt(dv, ctx);
                 if (qmm_moe_router_supported(&lg, &ids, &w, n_used)) {
                     if (qmm_moe_router(ctx->dev->qmm, &lg, &ids, &w, n_used, 1, qmm_stream(ctx->dev->qmm))) {

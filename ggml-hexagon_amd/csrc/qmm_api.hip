@@ -48,6 +48,7 @@ static int launch_matvec_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, c
     nw = nw >= 16 ? 16 : nw > 8 ? 16 : nw > 4 ? 8 : 4;
     int blocks = (total + nw - 1) / nw;
     if (blocks > c->cus * c->mv_bpc) blocks = c->cus * c->mv_bpc;
+    QMM_TRACE(c, "matvec_kernel<%d,%d,%s>", T, NTOK, group_has_extras(g) ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * WAVE), lds, st, g, x, ldx, K, c->act_mode);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
@@ -64,6 +65,7 @@ static int launch_kmix_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, con
     nw = nw > 8 ? 16 : nw > 4 ? 8 : 4;
     int blocks = (total + nw - 1) / nw;
     if (blocks > c->cus * c->mv_bpc) blocks = c->cus * c->mv_bpc;
+    QMM_TRACE(c, "matvec_kmix_kernel<%d,%s>", NTOK, group_has_extras(g) ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * WAVE), lds, st, g, x, ldx, K, c->act_mode);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
@@ -167,6 +169,7 @@ static int chain_launch(qmm_ctx * c) {
                 if (e != hipSuccess) { rc = fail(QMM_EHIP, "chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); break; }
                 c->chain_attr_set = true;
             }
+            QMM_TRACE(c, "matvec_chain_kernel<1>");
             hipLaunchKernelGGL(kern, dim3(c->cus), dim3(CHAIN_NW * WAVE), total, st, a);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { rc = fail(QMM_EHIP, "chain launch: %s", hipGetErrorString(e)); break; }
@@ -317,6 +320,7 @@ void qmm_destroy(qmm_ctx * c) {
     if (c->flag) (void) hipFree(c->flag);
     if (c->chain_sync) (void) hipFree(c->chain_sync);
     delete c->chain;
+    delete c->trace;
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -804,6 +808,26 @@ int qmm_chain_debug(qmm_ctx * c, void * stamps) {
     c->chain_dbg = (uint64_t *) stamps;
     return QMM_OK;
 }
+int qmm_trace_begin(qmm_ctx * c) {
+    if (!c) return fail(QMM_EINVAL, "qmm_trace_begin: NULL context");
+    if (!c->trace) c->trace = new std::string();
+    c->trace->clear();
+    return QMM_OK;
+}
+
+int qmm_trace_end(qmm_ctx * c, char * buf, size_t len) {
+    if (!c || !c->trace) return fail(QMM_EINVAL, "qmm_trace_end: no trace in progress");
+    int n = 0;
+    for (char ch : *c->trace) n += ch == ';';
+    if (buf && len) {
+        snprintf(buf, len, "%s", c->trace->c_str());
+        if (c->trace->size() >= len) n = fail(QMM_EINVAL, "qmm_trace_end: %zu bytes of labels do not fit the buffer", c->trace->size());
+    }
+    delete c->trace;
+    c->trace = nullptr;
+    return n;
+}
+
 int qmm_chain_stats(const qmm_ctx * c, int * launches, int * steps) {
     if (!c) return fail(QMM_EINVAL, "qmm_chain_stats: NULL context");
     if (launches) *launches = c->chain_launches;

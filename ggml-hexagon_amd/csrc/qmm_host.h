@@ -50,6 +50,9 @@ struct qmm_ctx {
     int         chain_checked = 0;   // chain_launches when the error word was last read
     hipStream_t chain_stream = nullptr;         // stream of the recorded steps
     char        name[128] = {0};
+    // qmm_trace_begin / qmm_trace_end: while set, every kernel launch of the MUL_MAT path appends its label here (host side only;
+    // bench.py buckets its roofline by the kernels a call actually issued, not by a replica of the dispatch rules)
+    std::string * trace = nullptr;
 
     // `st` is used verbatim: NULL is HIP's default stream (what torch's default stream is), not ours
     hipStream_t s(void * st) const { return (hipStream_t) st; }
@@ -61,6 +64,11 @@ int qmm_internal_chain_flush(qmm_ctx * c);
 #define QMM_CHAIN_FLUSH(c)                                                      \
     do {                                                                        \
         if ((c)->chain_on) { int rc_ = qmm_internal_chain_flush(c); if (rc_) return rc_; } \
+    } while (0)
+
+#define QMM_TRACE(c, ...)                                                                   \
+    do {                                                                                    \
+        if ((c)->trace) { char b_[96]; snprintf(b_, sizeof(b_), __VA_ARGS__); (c)->trace->append(b_).push_back(';'); } \
     } while (0)
 
 namespace qmm {

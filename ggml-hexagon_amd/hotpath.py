@@ -117,37 +117,52 @@ class HotPath:
             if chain:
                 q.chain_end()
 
-    def _issue(self, q, io_all, io_out):
-        for grp in self.wl.groups:
-            x, dst_local, dst_full, ids = io_out if grp.outputs_only else io_all
-            m0 = grp.mats[0]
-            if m0.n_expert:
-                ne11 = m0.n_used if m0.name.endswith("down_exps") else 1
-                outs = [dst_local[("id", m.name.split(".")[-1], m.M)] for m in grp.mats]
-                if len(grp.mats) == 2 and grp.mats[1].type == m0.type:      # ffn_gate_exps + ffn_up_exps: same b, same ids
-                    q.mul_mat_id_pair(self.types[m0.name], self.weights[grp.mats[0].name][0], self.weights[grp.mats[1].name][0], m0.K,
-                                      x[(m0.K, ne11)], ids[:, :m0.n_used], outs[0], outs[1])
-                else:
-                    for m, o in zip(grp.mats, outs):
-                        q.mul_mat_id(self.types[m.name], self.weights[m.name][0], m.K, x[(m.K, ne11)], ids[:, :m.n_used], out=o)
-                continue
-            ws, outs, keys = [], [], []
-            for m in grp.mats:
-                w, ranges = self.weights[m.name]
-                dkey = (m.name.split(".")[-1], w.shape[0])
-                ws.append((self.types[m.name], w))
-                outs.append(dst_local[dkey])
-                keys.append((dkey, ranges))
-            gkey = ("group",) + tuple(dkey for dkey, _ in keys)
-            if self.split and gkey in dst_local:
-                buf, outs = dst_local[gkey]
-                q.mul_mat_group(ws, m0.K, x[m0.K], outs)
-                self.concat.concat_group(buf, [dkey[1] for dkey, _ in keys], [r for _, r in keys], [dst_full[dkey] for dkey, _ in keys])
-                continue
-            q.mul_mat_group(ws, m0.K, x[m0.K], outs)
-            if self.split:
+    def group_call(self, grp, io):
+        """the launches of ONE group of the pass as a closure: what `_issue` runs and what bench.py's roofline leg times, so the two
+        cannot drift apart (the leg used to cut q/k/v into same-type runs that the timed pass never issues)"""
+        q = self.q
+        x, dst_local, dst_full, ids = io
+        m0 = grp.mats[0]
+        if m0.n_expert:
+            ne11 = m0.n_used if m0.name.endswith("down_exps") else 1
+            outs = [dst_local[("id", m.name.split(".")[-1], m.M)] for m in grp.mats]
+            if len(grp.mats) == 2 and grp.mats[1].type == m0.type:      # ffn_gate_exps + ffn_up_exps: same b, same ids
+                t, w0, w1, xx, ii = self.types[m0.name], self.weights[grp.mats[0].name][0], self.weights[grp.mats[1].name][0], x[(m0.K, ne11)], ids[:, :m0.n_used]
+                return lambda: q.mul_mat_id_pair(t, w0, w1, m0.K, xx, ii, outs[0], outs[1])
+            calls = [(self.types[m.name], self.weights[m.name][0], m.K, x[(m.K, ne11)], ids[:, :m.n_used], o) for m, o in zip(grp.mats, outs)]
+
+            def run_ids():
+                for t, w, k, xx, ii, o in calls:
+                    q.mul_mat_id(t, w, k, xx, ii, out=o)
+            return run_ids
+        ws, outs, keys = [], [], []
+        for m in grp.mats:
+            w, ranges = self.weights[m.name]
+            dkey = (m.name.split(".")[-1], w.shape[0])
+            ws.append((self.types[m.name], w))
+            outs.append(dst_local[dkey])
+            keys.append((dkey, ranges))
+        gkey = ("group",) + tuple(dkey for dkey, _ in keys)
+        xk = x[m0.K]
+        if self.split and gkey in dst_local:
+            buf, gouts = dst_local[gkey]
+            cols, rngs, fulls = [dkey[1] for dkey, _ in keys], [r for _, r in keys], [dst_full[dkey] for dkey, _ in keys]
+
+            def run_split_group():
+                q.mul_mat_group(ws, m0.K, xk, gouts)
+                self.concat.concat_group(buf, cols, rngs, fulls)
+            return run_split_group
+        if self.split:
+            def run_split():
+                q.mul_mat_group(ws, m0.K, xk, outs)
                 for (dkey, ranges), o in zip(keys, outs):
                     self.concat.concat(o, ranges, out=dst_full[dkey])
+            return run_split
+        return lambda: q.mul_mat_group(ws, m0.K, xk, outs)
+
+    def _issue(self, q, io_all, io_out):
+        for grp in self.wl.groups:
+            self.group_call(grp, io_out if grp.outputs_only else io_all)()
 
     def capture(self, n_tokens: int):
         """hipGraph of one pass: removes the per-launch host cost from the token-generation loop.  With a row split the RCCL

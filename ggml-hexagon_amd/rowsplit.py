@@ -7,12 +7,24 @@ every rank computes dst[:, row_low:row_high] and the slices are gathered over RC
 """
 from __future__ import annotations
 
-ROW_ROUNDING = 64        # mat-vec: one row per wave, MFMA tiles: 64/128 weight rows
+ROW_ROUNDING = 256       # the prefill kernels' row tile and the plugin's SPLIT_ROW_ROUNDING (ggml-mi355x.cpp): a slice never starts inside a 256-row tile
 
 
-def row_range(nrows: int, rank: int, world: int, tensor_split=None, rounding: int = ROW_ROUNDING):
+def rounding_for(nrows: int, world: int, rounding: int = ROW_ROUNDING) -> int:
+    """the row rounding of one matrix: ROW_ROUNDING where every rank still gets rows, else the largest power of two (>= 32) that
+    leaves none empty.  A 1024-row wk / wv over 8 ranks would otherwise come out as 0 / 256 / 0 / 256 ... rows: half
+    the devices idle on it and the group's slices stop being equal, which costs the one-all-gather-per-group exchange."""
+    r = rounding
+    while r > 32 and nrows // world < r:
+        r //= 2
+    return r
+
+
+def row_range(nrows: int, rank: int, world: int, tensor_split=None, rounding: int | None = None):
     if tensor_split is None:
         tensor_split = [i / world for i in range(world)]           # equal devices: cumulative starts
+    if rounding is None:
+        rounding = rounding_for(nrows, world)
     lo = int(nrows * tensor_split[rank])
     lo -= lo % rounding
     if rank == world - 1:
@@ -23,7 +35,7 @@ def row_range(nrows: int, rank: int, world: int, tensor_split=None, rounding: in
     return lo, hi
 
 
-def all_ranges(nrows: int, world: int, tensor_split=None, rounding: int = ROW_ROUNDING):
+def all_ranges(nrows: int, world: int, tensor_split=None, rounding: int | None = None):
     return [row_range(nrows, r, world, tensor_split, rounding) for r in range(world)]
 
 

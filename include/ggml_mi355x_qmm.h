@@ -197,6 +197,14 @@ QMM_API int qmm_chain_stats(const qmm_ctx * ctx, int * persistent_launches, int 
  * launches behind each other); NULL switches it off.  profiles/tools/chain_stamps.py reads them. */
 QMM_API int qmm_chain_debug(qmm_ctx * ctx, void * stamps);
 
+/* Which kernels did a call issue?  Between qmm_trace_begin and qmm_trace_end every kernel launch of the MUL_MAT / MUL_MAT_ID entry
+ * points appends its name (template arguments as rocprofv3 prints them, ';' behind each) to a host-side list; qmm_trace_end copies the
+ * list into buf and returns the number of launches (< 0: error).  Host bookkeeping only, nothing on the device changes.  bench.py
+ * buckets its roofline by these labels, so the figures describe the launches the timed pass issues (ggml has no counterpart: its CPU
+ * backend has one code path per type, ggml-cpu.c:6745-6937). */
+QMM_API int qmm_trace_begin(qmm_ctx * ctx);
+QMM_API int qmm_trace_end(qmm_ctx * ctx, char * buf, size_t len);
+
 /* dst = W * (silu(gate) .* up) for a prompt batch (N > QMM_MATVEC_MAX_N): ffn_down with build_ffn's SwiGLU product formed by the
  * activation prep of the MFMA path; gate / up rows are ld_gate / ld_up floats apart.  Default prefill precision only. */
 QMM_API int qmm_mul_mat_swiglu_in(qmm_ctx * ctx, int type, const void * w, int64_t w_row_bytes, int64_t K, int64_t M,

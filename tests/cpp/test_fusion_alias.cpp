@@ -10,6 +10,7 @@
 #include "ggml-backend.h"
 #include "ggml-cpu.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +69,63 @@ static ggml_tensor * weight(Graph & G, std::mt19937 & rng, ggml_type type, int64
     G.fresh(t);
     G.init.push_back({ t, q });
     return t;
+}
+
+static ggml_tensor * weight3(Graph & G, std::mt19937 & rng, ggml_type type, int64_t k, int64_t m, int64_t e, float sigma) {
+    ggml_tensor * t = ggml_new_tensor_3d(G.ctx, type, k, m, e);
+    std::uniform_real_distribution<float> u(-sigma, sigma);
+    std::vector<float> f((size_t) k * m * e);
+    for (auto & v : f) v = u(rng);
+    std::vector<uint8_t> q(ggml_row_size(type, k) * m * e);
+    ggml_quantize_chunk(type, f.data(), q.data(), 0, m * e, k, nullptr);
+    G.fresh(t);
+    G.init.push_back({ t, q });
+    return t;
+}
+
+// build_moe_ffn (src/llama-graph.cpp:800-917) with softmax gating and normalised weights, as Mixtral runs it.  `where` picks the forced
+// placement: 1 = the DIV (normalised weights, rows of 4 * n_used bytes) ON the router logits (dead at the div's place in the graph,
+// still read by the fused router launch, rows of 4 * n_expert bytes); 2 = the argsort's ids exactly on the logits (same rows: a wave
+// reads its row before it writes it, legal in place); 3 = the ids one row further; 4 = the last expert ADD on the expert outputs (the
+// operand of the fused combine launch); 5 = the last ADD on the weights
+static void moe_block(Graph & G, std::mt19937 & rng, int64_t N, int where) {
+    const int64_t E = 1024, F = 512, NE = 8, NU = 2;
+    ggml_tensor * x = weight(G, rng, GGML_TYPE_F32, E, N, 1.0f);
+    ggml_tensor * gi = weight(G, rng, GGML_TYPE_F32, E, NE, 0.05f);
+    ggml_tensor * up_e = weight3(G, rng, GGML_TYPE_Q4_K, E, F, NE, 0.05f), * gate_e = weight3(G, rng, GGML_TYPE_Q4_K, E, F, NE, 0.05f);
+    ggml_tensor * down_e = weight3(G, rng, GGML_TYPE_Q4_K, F, E, NE, 0.05f);
+    // two spare regions nobody reads: the forced placements go there, so that a shifted or oversized tensor never runs into a live one
+    ggml_tensor * spare = weight(G, rng, GGML_TYPE_F32, E, N + 1, 1.0f), * spare2 = weight(G, rng, GGML_TYPE_F32, E, N + 1, 1.0f);
+    size_t o_logits = 0, o_dv = 0;
+    for (auto & p : G.place) { if (p.t == spare) o_logits = p.off; if (p.t == spare2) o_dv = p.off; }
+    ggml_tensor * logits = ggml_mul_mat(G.ctx, gi, x);                              G.at(logits, o_logits);
+    ggml_tensor * probs = ggml_soft_max(G.ctx, logits);                             G.fresh(probs);
+    ggml_tensor * sel = ggml_top_k(G.ctx, probs, NU);                               // argsort + view
+    ggml_tensor * as = sel->src[0];
+    if (where == 2) G.at(as, o_logits); else if (where == 3) G.at(as, o_logits + NE * 4); else G.fresh(as);
+    ggml_tensor * wts = ggml_get_rows(G.ctx, ggml_reshape_3d(G.ctx, probs, 1, NE, N), sel);   G.fresh(wts);
+    ggml_tensor * w2 = ggml_reshape_2d(G.ctx, wts, NU, N);
+    ggml_tensor * ws = ggml_sum_rows(G.ctx, w2);                                    G.fresh(ws);
+    ggml_tensor * dv = ggml_div(G.ctx, w2, ws);                                     G.at(dv, where == 1 ? o_logits : o_dv);
+    ggml_tensor * w3 = ggml_reshape_3d(G.ctx, dv, 1, NU, N);
+    ggml_tensor * cur = ggml_reshape_3d(G.ctx, x, E, 1, N);
+    ggml_tensor * up = ggml_mul_mat_id(G.ctx, up_e, cur, sel);                      G.fresh(up);
+    ggml_tensor * gate = ggml_mul_mat_id(G.ctx, gate_e, cur, sel);                  G.fresh(gate);
+    ggml_tensor * sl = ggml_silu(G.ctx, gate);                                      G.fresh(sl);
+    ggml_tensor * par = ggml_mul(G.ctx, up, sl);                                    G.fresh(par);
+    ggml_tensor * ex = ggml_mul_mat_id(G.ctx, down_e, par, sel);                    const size_t o_ex = G.fresh(ex);
+    ggml_tensor * exw = ggml_mul(G.ctx, ex, w3);                                    G.fresh(exw);
+    ggml_tensor * out = nullptr;
+    for (int i = 0; i < NU; ++i) {
+        ggml_tensor * ce = ggml_view_2d(G.ctx, exw, E, N, exw->nb[2], i * exw->nb[1]);
+        if (i == 0) { out = ce; continue; }
+        out = ggml_add(G.ctx, out, ce);
+        if (i == NU - 1 && where == 4) G.at(out, o_ex);                             // on the expert outputs ([E, NU, N]: the sum fits)
+        else if (i == NU - 1 && where == 5) G.at(out, o_dv);                        // on the weights (8 N bytes at the start of spare2)
+        else G.fresh(out);
+    }
+    ggml_tensor * fin = ggml_scale(G.ctx, out, 1.0f);                               G.fresh(fin);
+    G.outs = { fin };
 }
 
 static void compare(const char * what, int64_t n, ggml_backend_t gpu, ggml_backend_t cpu, const std::function<void(Graph &, std::mt19937 &)> & build) {
@@ -161,6 +219,13 @@ int main() {
                 ggml_tensor * fin = ggml_scale(G.ctx, ct, 1.0f);               G.fresh(fin);
                 G.outs = { fin };
             });
+        // 7.-11. build_moe_ffn: the router launch (soft_max .. div in one) and the combine launch (experts * weights + the adds in one)
+        // with their early-written results forced onto operands of the same launch
+        const char * moe_what[] = { "MoE block, free placement", "normalised weights (DIV) placed on the router logits", "argsort ids placed exactly on the logits",
+                                    "argsort ids placed on the logits, one row further", "last expert ADD placed on the expert outputs",
+                                    "last expert ADD placed on the expert weights" };
+        for (int where = 0; where <= 5; ++where)
+            compare(moe_what[where], N, gpu, cpu, [&](Graph & G, std::mt19937 & rng) { moe_block(G, rng, N, where); });
     }
     ggml_backend_free(gpu);
     ggml_backend_free(cpu);

@@ -57,6 +57,7 @@ struct Recipe {
     int n_embd, n_head, n_head_kv, head_dim, n_ff, n_tokens, n_layer;
     bool bias, qk_norm, parallel_residual, gated, gelu, scale_residual, second_reader, post_norm;
     ggml_type tq, tk, tv, to, tg, tu, td;
+    int n_expert, n_used;                    // > 0: the MLP is build_moe_ffn's block (router, MUL_MAT_IDs, weighted sum of the used experts)
 };
 
 static Recipe draw(uint32_t seed) {
@@ -79,16 +80,21 @@ static Recipe draw(uint32_t seed) {
         const ggml_type legacy[] = { GGML_TYPE_Q4_0, GGML_TYPE_Q4_1, GGML_TYPE_Q5_0, GGML_TYPE_Q5_1, GGML_TYPE_Q8_0, GGML_TYPE_IQ4_NL };
         c.to = legacy[r.pick(6)];
     }
+    // drawn last, so that the seeds of the rounds before keep their graphs: a quarter of the graphs get Mixtral's MoE block
+    c.n_expert = r.coin(25) ? (r.coin() ? 8 : 4) : 0;
+    c.n_used = c.n_expert ? 2 + r.pick(2) : 0;
+    if (c.n_expert) { c.gated = true; c.tu = c.tg; }
     return c;
 }
 
 static std::string describe(const Recipe & c) {
-    char b[512];
-    snprintf(b, sizeof(b), "seed %u: %d layer(s), embd %d, heads %d/%d x %d, ff %d, N %d, q/k/v/o %s/%s/%s/%s, gate/up/down %s/%s/%s%s%s%s%s%s%s%s%s",
+    char b[576], moe[48] = "";
+    if (c.n_expert) snprintf(moe, sizeof(moe), ", MoE %d of %d experts", c.n_used, c.n_expert);
+    snprintf(b, sizeof(b), "seed %u: %d layer(s), embd %d, heads %d/%d x %d, ff %d, N %d, q/k/v/o %s/%s/%s/%s, gate/up/down %s/%s/%s%s%s%s%s%s%s%s%s%s",
              c.seed, c.n_layer, c.n_embd, c.n_head, c.n_head_kv, c.head_dim, c.n_ff, c.n_tokens, ggml_type_name(c.tq), ggml_type_name(c.tk),
              ggml_type_name(c.tv), ggml_type_name(c.to), ggml_type_name(c.tg), ggml_type_name(c.tu), ggml_type_name(c.td), c.bias ? ", biases" : "",
              c.qk_norm ? ", QK-norm" : "", c.parallel_residual ? ", parallel residual" : "", c.gated ? "" : ", ungated MLP", c.gelu ? ", GELU" : "",
-             c.scale_residual ? ", scaled residual" : "", c.second_reader ? ", extra readers" : "", c.post_norm ? ", post-norm" : "");
+             c.scale_residual ? ", scaled residual" : "", c.second_reader ? ", extra readers" : "", c.post_norm ? ", post-norm" : "", moe);
     return b;
 }
 
@@ -109,6 +115,15 @@ static bool build(const Recipe & c, ggml_backend_t be, Built & B) {
         std::vector<uint8_t> q(ggml_row_size(type, k) * m);
         if (type == GGML_TYPE_F32) memcpy(q.data(), f.data(), q.size());
         else ggml_quantize_chunk(type, f.data(), q.data(), 0, m, k, nullptr);
+        pend.push_back({ t, std::move(q) });
+        return t;
+    };
+    auto weight3 = [&](ggml_type type, int64_t k, int64_t m, int64_t e, float sigma) {
+        ggml_tensor * t = ggml_new_tensor_3d(cw, type, k, m, e);
+        std::vector<float> f((size_t) k * m * e);
+        for (auto & v : f) v = r.uni() * sigma;
+        std::vector<uint8_t> q(ggml_row_size(type, k) * m * e);
+        ggml_quantize_chunk(type, f.data(), q.data(), 0, m * e, k, nullptr);
         pend.push_back({ t, std::move(q) });
         return t;
     };
@@ -155,7 +170,29 @@ static bool build(const Recipe & c, ggml_backend_t be, Built & B) {
         if (c.parallel_residual) { h = nullptr; ffn_in = norm(resid, E); }         // gpt-neox: both branches read the layer input
         else { h = ggml_add(cg, att, resid); ffn_in = norm(h, E); }
         ggml_tensor * f;
-        if (c.gated) {
+        if (c.n_expert) {
+            // build_moe_ffn (src/llama-graph.cpp:800-917): softmax gating, top-k, normalised weights, SiLU experts, sum over the used ones
+            const int64_t NE = c.n_expert, NU = c.n_used;
+            ggml_tensor * lg = ggml_mul_mat(cg, weight(GGML_TYPE_F32, E, NE, 1.0f), ffn_in);
+            ggml_tensor * probs = ggml_soft_max(cg, lg);
+            ggml_tensor * sel = ggml_top_k(cg, probs, (int) NU);
+            ggml_tensor * wts = ggml_get_rows(cg, ggml_reshape_3d(cg, probs, 1, NE, N), sel);
+            wts = ggml_reshape_2d(cg, wts, NU, N);
+            wts = ggml_div(cg, wts, ggml_sum_rows(cg, wts));
+            wts = ggml_reshape_3d(cg, wts, 1, NU, N);
+            ggml_tensor * x3 = ggml_reshape_3d(cg, ffn_in, E, 1, N);
+            ggml_tensor * up = ggml_mul_mat_id(cg, weight3(c.tu, E, F, NE, ws), x3, sel);
+            ggml_tensor * gt = ggml_mul_mat_id(cg, weight3(c.tg, E, F, NE, ws), x3, sel);
+            gt = ggml_silu(cg, gt);
+            ggml_tensor * par = ggml_mul(cg, up, gt);
+            ggml_tensor * ex = ggml_mul_mat_id(cg, weight3(c.td, F, E, NE, 1.0f / sqrtf((float) F)), par, sel);
+            ex = ggml_mul(cg, ex, wts);
+            f = nullptr;
+            for (int64_t u = 0; u < NU; ++u) {
+                ggml_tensor * ce = ggml_view_2d(cg, ex, E, N, ex->nb[2], u * ex->nb[1]);
+                f = u == 0 ? ce : ggml_add(cg, f, ce);
+            }
+        } else if (c.gated) {
             ggml_tensor * g = ggml_mul_mat(cg, weight(c.tg, E, F, ws), ffn_in);
             ggml_tensor * u = ggml_mul_mat(cg, weight(c.tu, E, F, ws), ffn_in);
             if (c.second_reader && il == c.n_layer - 1) { ggml_tensor * o = ggml_scale(cg, u, 2.0f); ggml_set_output(o); B.outs.push_back(o); }   // `up` is read twice
@@ -166,7 +203,7 @@ static bool build(const Recipe & c, ggml_backend_t be, Built & B) {
             if (c.bias) f = ggml_add(cg, f, weight(GGML_TYPE_F32, F, 1, 0.1f));
             f = c.gelu ? ggml_gelu(cg, f) : ggml_silu(cg, f);
         }
-        f = ggml_mul_mat(cg, weight(c.td, F, E, 1.0f / sqrtf((float) F)), f);
+        if (!c.n_expert) f = ggml_mul_mat(cg, weight(c.td, F, E, 1.0f / sqrtf((float) F)), f);
         if (c.post_norm) f = norm(f, E);                                           // gemma-style norm behind the block
         cur = c.parallel_residual ? ggml_add(cg, ggml_add(cg, f, att), resid) : ggml_add(cg, f, h);
     }

@@ -74,15 +74,23 @@ def test_workload_accounting_matches_survey():
 
 
 def test_row_ranges_follow_ggml_row_split():
-    from ggml_hexagon_amd.rowsplit import all_ranges, row_range
-    for m in (4096, 14336, 128256, 1024, 100):
+    from ggml_hexagon_amd.rowsplit import ROW_ROUNDING, all_ranges, rounding_for, row_range
+    assert ROW_ROUNDING == 256                               # the prefill kernels' row tile = the plugin's SPLIT_ROW_ROUNDING
+    for m in (4096, 14336, 28672, 128256, 1024, 100):
         for world in (1, 2, 4, 8):
             rs = all_ranges(m, world)
+            rnd = rounding_for(m, world)
             assert rs[0][0] == 0 and rs[-1][1] == m
             for (lo, hi), (lo2, _) in zip(rs, rs[1:]):
-                assert hi == lo2 and lo % 64 == 0
-    assert row_range(128256, 7, 8) == (112192, 128256)       # the last device takes the remainder (ggml-cuda.cu:740-753)
-    assert all_ranges(100, 4) == [(0, 0), (0, 0), (0, 64), (64, 100)]
+                assert hi == lo2 and lo % rnd == 0
+            if m // world >= 32:                             # no rank left without rows where 32-row slices exist (1024 rows on 8 ranks)
+                assert all(hi > lo for lo, hi in rs), (m, world, rs)
+    assert rounding_for(1024, 8) == 128 and rounding_for(8192, 8) == 256 and rounding_for(1024, 2) == 256
+    assert all_ranges(1024, 8) == [(128 * i, 128 * i + 128) for i in range(8)]
+    # cumulative fractions rounded DOWN to the rounding, the last device takes the remainder (ggml-cuda.cu:740-753)
+    assert row_range(128256, 7, 8) == (112128, 128256)
+    assert row_range(128256, 7, 8, rounding=64) == (112192, 128256)
+    assert all_ranges(100, 4, rounding=64) == [(0, 0), (0, 0), (0, 64), (64, 100)]
 
 
 def _free_port():
