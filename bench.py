@@ -146,6 +146,10 @@ class LlamaBench:
                     out["gpu_ms_per_token"] = round(mtg / max(ntg, 1), 4)
                     # the fastest prompt graph: the warm-up pass also re-lays weights at their first use (and loads code objects)
                     out["gpu_ms_per_prompt_batch"] = round(float(m.group(6)) if m.group(6) else mpp / max(npp, 1), 3)
+                h = re.search(r"host us per tg graph: outside graph_compute ([0-9.]+) \| reader analysis ([0-9.]+) \| issue loop ([0-9.]+) \| waiting in synchronize ([0-9.]+)", err)
+                if h:       # where the host's wall time goes around a one-token graph (the GPU idles during `outside` + `analysis`)
+                    out["host_us_per_token"] = {"outside_graph_compute": float(h.group(1)), "reader_analysis": float(h.group(2)),
+                                                "issue_loop": float(h.group(3)), "waiting_in_synchronize": float(h.group(4))}
             return out
         except Exception as e:              # reported-only
             return {"pp512_tok_s": None, "tg128_tok_s": None, "threads": threads, "error": f"{type(e).__name__}: {str(e)[-300:]}"}
@@ -311,6 +315,17 @@ def main():
             if int(ok.item()) == 0:
                 graph = None
 
+    # the prompt pass as a hipGraph too (one GPU): its ~430 launches leave a Python host ~25 us each, which a slow or shared host
+    # does not have (round 3: the same kernels gave 11.9 ms GPU-bound and 21.9 ms issued eagerly from one box's host)
+    graph_pp = None
+    if use_graph and world == 1 and not force_split and os.environ.get("QMM_BENCH_GRAPH_PP", "1") != "0":
+        try:
+            graph_pp = hp.capture(args.n_prompt, n_out_pp)
+        except Exception as e:                       # noqa: BLE001
+            print(f"[bench] hipGraph capture of the prompt pass failed ({type(e).__name__}: {e}); running it eager", file=sys.stderr)
+            graph_pp = None
+            torch.cuda.synchronize()
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -320,7 +335,10 @@ def main():
 
     def step(e=None):
         if e: e[0].record()
-        hp.run(args.n_prompt, n_out_pp)
+        if graph_pp is not None:
+            graph_pp.replay()
+        else:
+            hp.run(args.n_prompt, n_out_pp)
         if e: e[1].record()
         for _ in range(args.n_gen):
             if graph is not None:
@@ -411,7 +429,7 @@ def main():
                                + ("logits for every token" if args.all_logits else "n_outputs = 1 as llama-bench runs it (last layer's FFN and the output projection on one row)"),
                    "n_prompt": args.n_prompt, "n_gen": args.n_gen, "n_outputs_pp": args.n_prompt if args.all_logits else 1,
                    "parallelism": "single GPU" if world == 1 else f"ggml row split over {world} GPUs, RCCL all-gather concat",
-                   "tg_launch": "hipGraph replay" if graph is not None else "eager",
+                   "tg_launch": "hipGraph replay" if graph is not None else "eager", "pp_launch": "hipGraph replay" if graph_pp is not None else "eager",
                    "weight_layout": "GGUF wire" if args.wire_layout else "planar rows for Q4_0 / Q8_0 / Q6_K (in-place repack at upload, SURVEY 8f-2), GGUF wire otherwise"},
         "tg128_tok_s": round(tg_tok_s, 2), "pp512_tok_s": round(pp_tok_s, 2),
         "tg_ms_per_token": round(tg_s / args.n_gen * 1e3, 4), "pp_ms_per_batch": round(pp_s * 1e3, 3),

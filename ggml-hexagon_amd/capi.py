@@ -254,6 +254,23 @@ class Qmm:
         self._chk(self.lib.qmm_mul_mat_group(self.ctx, arr, len(weights), k, x.data_ptr(), x.shape[0], x.stride(0), self._stream()))
         return outs
 
+    def mul_mat_group_call(self, weights, k, x, outs):
+        """mul_mat_group with the argument marshalling done once: returns a closure that issues the call on the current stream
+        (bench.py's passes repeat the same 129 calls; rebuilding the ctypes array per call made the eager prompt pass host-bound on a
+        slow host)"""
+        arr = (QmmWeight * len(weights))()
+        for i, ((t, w), o) in enumerate(zip(weights, outs)):
+            arr[i] = QmmWeight(w.data_ptr(), w.stride(0), w.shape[0], o.data_ptr(), o.stride(0), t)
+        n, xp, nt, ldx, fn, ctx = len(weights), x.data_ptr(), x.shape[0], x.stride(0), self.lib.qmm_mul_mat_group, self.ctx
+        keep = (weights, x, outs)                                   # the closure owns the buffers it points into
+
+        def call():
+            rc = fn(ctx, arr, n, k, xp, nt, ldx, self._stream())
+            if rc:
+                self._chk(rc)
+            return keep[2]
+        return call
+
     def mul_mat_group_ex(self, weights, k, x, outs, norm_w=None, eps=0.0, residuals=None, swiglu=0):
         """qmm_mul_mat_group_ex: x -> rms_norm(x, eps) * norm_w while staging (optional), outs[i] = W_i x + residuals[i] (optional)"""
         arr = (QmmWeight * len(weights))()

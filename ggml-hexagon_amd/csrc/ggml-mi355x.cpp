@@ -27,6 +27,7 @@
 #include <array>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -89,6 +90,9 @@ struct mi355x_backend_ctx {
     qmm_event *                      ev_t0 = nullptr, * ev_t1 = nullptr;
     double                           ms_tg = 0, ms_pp = 0, ms_pp_min = 0;      // (min: the warm-up pass also repacks weights at their first use)
     int64_t                          graphs_tg = 0, graphs_pp = 0, tokens_pp = 0;
+    // ... and where the HOST's time goes around one-token graphs (wall clock, us): between two graph_compute calls (libllama: graph
+    // build, scheduler, input copies, sampling-free bookkeeping), in the reader analysis, in the issue loop, waiting in synchronize
+    double                           us_outside = 0, us_analyze = 0, us_issue = 0, us_wait = 0, t_exit = 0;
 };
 
 // GGML_MI355X_GLUE=0: offload the quantized MUL_MAT / MUL_MAT_ID only (the round-1 surface); GGML_MI355X_FUSE=0: no fused pairs
@@ -1051,6 +1055,9 @@ void backend_free(ggml_backend_t backend) {
     if (ctx->ev_t0) {
         fprintf(stderr, "MI355X timing %s: tg graphs %lld stream_ms %.3f | pp graphs %lld tokens %lld stream_ms %.3f min_ms %.3f\n", ctx->name.c_str(),
                 (long long) ctx->graphs_tg, ctx->ms_tg, (long long) ctx->graphs_pp, (long long) ctx->tokens_pp, ctx->ms_pp, ctx->ms_pp_min);
+        if (ctx->graphs_tg > 1)
+            fprintf(stderr, "MI355X timing %s: host us per tg graph: outside graph_compute %.1f | reader analysis %.1f | issue loop %.1f | waiting in synchronize %.1f\n", ctx->name.c_str(),
+                    ctx->us_outside / (double) (ctx->graphs_tg - 1), ctx->us_analyze / (double) ctx->graphs_tg, ctx->us_issue / (double) ctx->graphs_tg, ctx->us_wait / (double) ctx->graphs_tg);
         qmm_event_destroy(ctx->dev->qmm, ctx->ev_t0);
         qmm_event_destroy(ctx->dev->qmm, ctx->ev_t1);
     }
@@ -1562,11 +1569,17 @@ int graph_pass::site_rope_kv_attention(int i, ggml_tensor * node, int gop) {
     return 0;
 }
 
+static double wall_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
-    analyze_readers(ctx, cgraph);
-    const int n_nodes = cgraph->n_nodes;
     const bool timing = GGML_MI355X_TIMING();
+    const double t_enter = timing ? wall_us() : 0;
+    analyze_readers(ctx, cgraph);
+    const double t_analyzed = timing ? wall_us() : 0;
+    const int n_nodes = cgraph->n_nodes;
     if (timing) {
         if (!ctx->ev_t0) { ctx->ev_t0 = qmm_event_create_timing(ctx->dev->qmm); ctx->ev_t1 = qmm_event_create_timing(ctx->dev->qmm); }
         if (ctx->ev_t0 && ctx->ev_t1) qmm_event_record(ctx->dev->qmm, ctx->ev_t0, qmm_stream(ctx->dev->qmm));
@@ -1674,6 +1687,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         }
     }
     if (timing && ctx->ev_t0 && ctx->ev_t1) qmm_event_record(ctx->dev->qmm, ctx->ev_t1, qmm_stream(ctx->dev->qmm));
+    const double t_issued = timing ? wall_us() : 0;
     // the scheduler reads results right after graph_compute/synchronize; a bad expert id surfaces here
     if (qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm))) {
         GGML_LOG_ERROR("MI355X graph_compute: %s\n", qmm_last_error());
@@ -1685,8 +1699,13 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         for (int i = 0; i < n_nodes; ++i)
             if (cgraph->nodes[i]->op == GGML_OP_MUL_MAT && cgraph->nodes[i]->ne[2] == 1) n_tok = std::max<int64_t>(n_tok, cgraph->nodes[i]->ne[1]);
         if (!qmm_event_elapsed_ms(ctx->dev->qmm, ctx->ev_t0, ctx->ev_t1, &ms)) {
-            if (n_tok == 1) { ctx->ms_tg += ms; ctx->graphs_tg++; }
-            else { ctx->ms_pp += ms; ctx->graphs_pp++; ctx->tokens_pp += n_tok; if (ctx->ms_pp_min == 0 || ms < ctx->ms_pp_min) ctx->ms_pp_min = ms; }
+            if (n_tok == 1) {
+                ctx->ms_tg += ms; ctx->graphs_tg++;
+                const double t_done = wall_us();
+                if (ctx->t_exit > 0) ctx->us_outside += t_enter - ctx->t_exit;
+                ctx->us_analyze += t_analyzed - t_enter;  ctx->us_issue += t_issued - t_analyzed;  ctx->us_wait += t_done - t_issued;
+                ctx->t_exit = t_done;
+            } else { ctx->t_exit = 0; ctx->ms_pp += ms; ctx->graphs_pp++; ctx->tokens_pp += n_tok; if (ctx->ms_pp_min == 0 || ms < ctx->ms_pp_min) ctx->ms_pp_min = ms; }
         }
     }
     return GGML_STATUS_SUCCESS;

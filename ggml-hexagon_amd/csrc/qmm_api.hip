@@ -6,6 +6,7 @@
 #include "qmm_matvec.hiph"
 #include "qmm_mfma.hiph"
 #include "qmm_mfma_regb.hiph"
+#include "qmm_mfma_r64s.hiph"
 #include "qmm_moe.hiph"
 #include "qmm_chain.hiph"
 
@@ -295,6 +296,8 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->wide = atoi(e);
     e = getenv("GGML_MI355X_R64");
     if (e) c->r64 = atoi(e);
+    e = getenv("GGML_MI355X_R64S");
+    if (e) c->r64s = atoi(e);
     e = getenv("GGML_MI355X_CHAIN");
     if (e) c->chain_enabled = atoi(e);
     e = getenv("GGML_MI355X_MV_BPC");

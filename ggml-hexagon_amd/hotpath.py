@@ -40,6 +40,7 @@ class HotPath:
                     self.weights[m.name] = (w, ranges)
                     self.types[m.name] = self._layout(m.type, w, m.K, planar)
         self.io = {}
+        self._calls = {}
         self.chain = False       # persistent chains for token generation (bench.py --chain): measured slower than launches, DESIGN.md
 
     def _layout(self, t, w, k, planar):
@@ -119,7 +120,15 @@ class HotPath:
 
     def group_call(self, grp, io):
         """the launches of ONE group of the pass as a closure: what `_issue` runs and what bench.py's roofline leg times, so the two
-        cannot drift apart (the leg used to cut q/k/v into same-type runs that the timed pass never issues)"""
+        cannot drift apart (the leg used to cut q/k/v into same-type runs that the timed pass never issues).  Built once
+        per (group, batch) and kept: the argument marshalling is not part of a pass."""
+        key = (id(grp), id(io))
+        fn = self._calls.get(key)
+        if fn is None:
+            fn = self._calls[key] = self._group_call(grp, io)
+        return fn
+
+    def _group_call(self, grp, io):
         q = self.q
         x, dst_local, dst_full, ids = io
         m0 = grp.mats[0]
@@ -144,33 +153,38 @@ class HotPath:
             keys.append((dkey, ranges))
         gkey = ("group",) + tuple(dkey for dkey, _ in keys)
         xk = x[m0.K]
+        # marshalling once where the binding offers it (capi.Qmm); any object with mul_mat_group will do (the CPU stand-in of the tests)
+        prepared = getattr(q, "mul_mat_group_call", None) or (lambda w_, k_, x_, o_: (lambda: q.mul_mat_group(w_, k_, x_, o_)))
         if self.split and gkey in dst_local:
             buf, gouts = dst_local[gkey]
             cols, rngs, fulls = [dkey[1] for dkey, _ in keys], [r for _, r in keys], [dst_full[dkey] for dkey, _ in keys]
+            mm = prepared(ws, m0.K, xk, gouts)
 
             def run_split_group():
-                q.mul_mat_group(ws, m0.K, xk, gouts)
+                mm()
                 self.concat.concat_group(buf, cols, rngs, fulls)
             return run_split_group
+        mm = prepared(ws, m0.K, xk, outs)
         if self.split:
             def run_split():
-                q.mul_mat_group(ws, m0.K, xk, outs)
+                mm()
                 for (dkey, ranges), o in zip(keys, outs):
                     self.concat.concat(o, ranges, out=dst_full[dkey])
             return run_split
-        return lambda: q.mul_mat_group(ws, m0.K, xk, outs)
+        return mm
 
     def _issue(self, q, io_all, io_out):
         for grp in self.wl.groups:
             self.group_call(grp, io_out if grp.outputs_only else io_all)()
 
-    def capture(self, n_tokens: int):
-        """hipGraph of one pass: removes the per-launch host cost from the token-generation loop.  With a row split the RCCL
-        all-gathers are captured with the launches (collectives are capturable; tests/test_gpu_rccl.py rehearses it on one GPU)"""
+    def capture(self, n_tokens: int, n_outputs=None):
+        """hipGraph of one pass: removes the per-launch host cost from the timed loops (token generation, and the prompt pass: ~430
+        launches from Python in 11 ms leave the host no slack).  With a row split the RCCL all-gathers are captured with the launches
+        (collectives are capturable; tests/test_gpu_rccl.py rehearses it on one GPU)"""
         self.prepare(n_tokens)
-        self.run(n_tokens)                  # warm: lazy module loads, workspace growth happen outside the capture
+        self.run(n_tokens, n_outputs)       # warm: lazy module loads, workspace growth happen outside the capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.run(n_tokens)
+            self.run(n_tokens, n_outputs)
         return g
