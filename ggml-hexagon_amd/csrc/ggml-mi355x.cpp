@@ -78,6 +78,7 @@ struct mi355x_backend_ctx {
     std::vector<redirect>            redirects;
     void *                           hoist_buf = nullptr;
     size_t                           hoist_bytes = 0, hoist_used = 0;
+    std::map<uintptr_t, uintptr_t>   later_ranges;   // analyze_readers: union of the byte ranges of the nodes behind the one looked at
     std::vector<const ggml_tensor *> skipped;
     std::vector<char>                done;
     std::vector<const ggml_tensor *> deferred;       // per node: the SILU whose result this MUL consumes in the same launch
@@ -211,13 +212,32 @@ void buffer_memset_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * ten
     if (qmm_memset(ctx->dev->qmm, (char *) tensor->data + offset, value, size, nullptr) || qmm_synchronize(ctx->dev->qmm, nullptr))
         GGML_ABORT("MI355X memset_tensor: %s", qmm_last_error());
 }
+// GGML_MI355X_TIMING=1: host wall time inside the module's transfer / synchronize entry points (what of libllama's time between two
+// graphs is spent here), summed per entry point
+bool GGML_MI355X_TIMING();
+struct host_timer {
+    static constexpr int N = 8;
+    static double us[N];
+    static long long calls[N];
+    static const char * name(int i) { static const char * n[N] = { "set_tensor", "get_tensor", "cpy_tensor", "set_tensor_async", "get_tensor_async", "cpy_tensor_async", "synchronize", "event" }; return n[i]; }
+    int slot; double t0;
+    explicit host_timer(int s) : slot(s), t0(GGML_MI355X_TIMING() ? std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0) {}
+    ~host_timer() {
+        if (t0 > 0) { us[slot] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; calls[slot]++; }
+    }
+};
+double host_timer::us[host_timer::N] = { 0 };
+long long host_timer::calls[host_timer::N] = { 0 };
+
 void buffer_set_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    host_timer timer_(0);
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
     planar_release(ctx, (const char *) tensor->data + offset, size, true, nullptr);       // wire bytes come in: the tensor is wire again
     if (qmm_memcpy_h2d(ctx->dev->qmm, (char *) tensor->data + offset, data, size, nullptr))
         GGML_ABORT("MI355X set_tensor: %s", qmm_last_error());
 }
 void buffer_get_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    host_timer timer_(1);
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
     planar_release(ctx, (const char *) tensor->data + offset, size, false, nullptr);      // wire bytes go out (converted again at the next use)
     if (qmm_memcpy_d2h(ctx->dev->qmm, data, (const char *) tensor->data + offset, size, nullptr))
@@ -225,6 +245,7 @@ void buffer_get_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * 
 }
 const char * buft_get_name(ggml_backend_buffer_type_t buft);
 bool buffer_cpy_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    host_timer timer_(2);
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
     ggml_backend_buffer_t sb = src->view_src ? src->view_src->buffer : src->buffer;
     if (!sb || sb->buft->iface.get_name != buft_get_name) return false;           // not one of ours: let ggml stage through the host
@@ -1055,6 +1076,9 @@ void backend_free(ggml_backend_t backend) {
     if (ctx->ev_t0) {
         fprintf(stderr, "MI355X timing %s: tg graphs %lld stream_ms %.3f | pp graphs %lld tokens %lld stream_ms %.3f min_ms %.3f\n", ctx->name.c_str(),
                 (long long) ctx->graphs_tg, ctx->ms_tg, (long long) ctx->graphs_pp, (long long) ctx->tokens_pp, ctx->ms_pp, ctx->ms_pp_min);
+        for (int i = 0; i < host_timer::N; ++i)
+            if (host_timer::calls[i]) fprintf(stderr, "MI355X timing %s: %s: %lld calls, %.1f us each, %.1f us per tg graph (all graphs' calls over the tg graphs)\n", ctx->name.c_str(),
+                                              host_timer::name(i), host_timer::calls[i], host_timer::us[i] / (double) host_timer::calls[i], host_timer::us[i] / (double) std::max<int64_t>(ctx->graphs_tg, 1));
         if (ctx->graphs_tg > 1)
             fprintf(stderr, "MI355X timing %s: host us per tg graph: outside graph_compute %.1f | reader analysis %.1f | issue loop %.1f | waiting in synchronize %.1f\n", ctx->name.c_str(),
                     ctx->us_outside / (double) (ctx->graphs_tg - 1), ctx->us_analyze / (double) ctx->graphs_tg, ctx->us_issue / (double) ctx->graphs_tg, ctx->us_wait / (double) ctx->graphs_tg);
@@ -1077,6 +1101,7 @@ bool on_device(const struct ggml_tensor * t, const mi355x_device_ctx * dev) {
     return b && b->buft->iface.get_name == buft_get_name && b->buft->context == (void *) dev;
 }
 void backend_set_tensor_async(ggml_backend_t backend, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    host_timer timer_(3);
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     GGML_ASSERT(on_device(tensor, ctx->dev) && "set_tensor_async: tensor is not in this device's buffer type");
     if (mi355x_buffer_ctx * bc = our_buffer_ctx(tensor)) planar_release(bc, (const char *) tensor->data + offset, size, true, qmm_stream(ctx->dev->qmm));
@@ -1084,6 +1109,7 @@ void backend_set_tensor_async(ggml_backend_t backend, struct ggml_tensor * tenso
         GGML_ABORT("MI355X set_tensor_async: %s", qmm_last_error());
 }
 void backend_get_tensor_async(ggml_backend_t backend, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    host_timer timer_(4);
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     GGML_ASSERT(on_device(tensor, ctx->dev) && "get_tensor_async: tensor is not in this device's buffer type");
     if (mi355x_buffer_ctx * bc = our_buffer_ctx(tensor)) planar_release(bc, (const char *) tensor->data + offset, size, false, qmm_stream(ctx->dev->qmm));
@@ -1092,6 +1118,7 @@ void backend_get_tensor_async(ggml_backend_t backend, const struct ggml_tensor *
 }
 ggml_guid_t backend_guid();
 bool backend_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backend_dst, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    host_timer timer_(5);
     if (!ggml_guid_matches(backend_src->guid, backend_guid()) || !ggml_guid_matches(backend_dst->guid, backend_guid())) return false;
     auto * sctx = (mi355x_backend_ctx *) backend_src->context;
     auto * dctx = (mi355x_backend_ctx *) backend_dst->context;
@@ -1121,6 +1148,7 @@ void backend_event_wait(ggml_backend_t backend, ggml_backend_event_t event) {
 }
 
 void backend_synchronize(ggml_backend_t backend) {
+    host_timer timer_(6);
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     if (qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm)))
         GGML_LOG_ERROR("MI355X synchronize: %s\n", qmm_last_error());
@@ -1164,6 +1192,36 @@ void analyze_readers(mi355x_backend_ctx * ctx, const ggml_cgraph * cgraph) {
                         it->glue_only = it->glue_only && (glue || (mm_src1 && j == 1 && it->t->op == GGML_OP_CONT));   // (only the merged-heads CONT is sent to the scratch on this account)
                     }
                 }
+            }
+            // Readers OUTSIDE this cgraph.  The scheduler hands a backend one split = a contiguous run of
+            // the graph's nodes; a tensor of this split may also be read by a later split (an op this device refuses inside a layer, a
+            // weight kept on the CPU with -ot: ggml-backend.cpp:1355-1448 copies such a tensor out of t->data after graph_compute).  The
+            // counts above see this split only, so a candidate counts as fully known only where that can be PROVEN: some later node of
+            // this cgraph owns memory that overlaps the candidate's.  ggml-alloc plans the whole graph at once and hands a block out
+            // again only behind its tensor's last reader anywhere, so every reader then lies between the two nodes, inside this
+            // split.  Anything else (nobody here reuses the block: typically the last tensors of a split) may have readers elsewhere: its
+            // count is poisoned, no site matches it, it is computed into its own t->data at its own place.
+            // One reverse sweep with the union of the later nodes' byte ranges (a compute arena: a handful of intervals).
+            std::map<uintptr_t, uintptr_t> & later = ctx->later_ranges;        // start -> end, disjoint
+            later.clear();
+            for (int i = cgraph->n_nodes - 1; i >= 0; --i) {
+                const ggml_tensor * n = cgraph->nodes[i];
+                if (!n->data || ggml_is_empty(n)) continue;
+                const uintptr_t a = (uintptr_t) n->data, b = a + ggml_nbytes(n);
+                auto it = std::lower_bound(rd.begin(), rd.end(), n, less);
+                if (it != rd.end() && it->t == n) {
+                    auto nx = later.upper_bound(a);                            // first interval starting behind a
+                    bool hit = nx != later.end() && nx->first < b;
+                    if (!hit && nx != later.begin()) { auto pv = std::prev(nx); hit = pv->second > a; }
+                    if (!hit) { it->uses = 1 << 20; it->glue_only = false; }
+                }
+                if (n->view_src) continue;                                     // views own nothing (in-place results are views of their operand)
+                // insert [a, b), merging what it touches
+                uintptr_t lo = a, hi = b;
+                auto f = later.upper_bound(lo);
+                if (f != later.begin() && std::prev(f)->second >= lo) { --f; lo = f->first; }
+                while (f != later.end() && f->first <= hi) { hi = std::max(hi, f->second); f = later.erase(f); }
+                later[lo] = hi;
             }
         }
     }

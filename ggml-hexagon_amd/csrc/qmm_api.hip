@@ -3,6 +3,8 @@
 
 #include "qmm_host.h"
 
+#include <algorithm>
+
 #include "qmm_matvec.hiph"
 #include "qmm_mfma.hiph"
 #include "qmm_mfma_regb.hiph"
@@ -271,6 +273,12 @@ qmm_ctx * qmm_create(int device) {
         delete c;
         return nullptr;
     }
+    c->kcnt_n = 1 << 16;
+    if (hipMalloc((void **) &c->kcnt, (size_t) c->kcnt_n * sizeof(int)) != hipSuccess || hipMemset(c->kcnt, 0, (size_t) c->kcnt_n * sizeof(int)) != hipSuccess) {
+        fail(QMM_EHIP, "qmm_create: split-K counters");
+        delete c;
+        return nullptr;
+    }
     c->chain = new std::vector<ChainStep>();
     if (hipMalloc((void **) &c->chain_sync, sizeof(ChainSync)) != hipSuccess || hipMemset(c->chain_sync, 0, sizeof(ChainSync)) != hipSuccess) {
         fail(QMM_EHIP, "qmm_create: chain state setup failed");
@@ -298,6 +306,10 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->r64 = atoi(e);
     e = getenv("GGML_MI355X_R64S");
     if (e) c->r64s = atoi(e);
+    e = getenv("GGML_MI355X_SIDE");
+    if (e) c->side_on = atoi(e);
+    e = getenv("GGML_MI355X_SPLITK_COMBINE");
+    if (e) c->splitk_combine = atoi(e);
     e = getenv("GGML_MI355X_CHAIN");
     if (e) c->chain_enabled = atoi(e);
     e = getenv("GGML_MI355X_MV_BPC");
@@ -321,9 +333,15 @@ void qmm_destroy(qmm_ctx * c) {
     (void) hipDeviceSynchronize();
     if (c->ws) (void) hipFree(c->ws);
     if (c->flag) (void) hipFree(c->flag);
+    if (c->kcnt) (void) hipFree(c->kcnt);
     if (c->chain_sync) (void) hipFree(c->chain_sync);
     delete c->chain;
     delete c->trace;
+    for (int l = 0; l < 3; ++l) {
+        if (c->side[l]) (void) hipStreamDestroy(c->side[l]);
+        if (c->ev_join[l]) (void) hipEventDestroy(c->ev_join[l]);
+    }
+    if (c->ev_fork) (void) hipEventDestroy(c->ev_fork);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -696,22 +714,73 @@ static int mul_mat_group_impl(qmm_ctx * c, const qmm_weight * ws, int nw, int64_
         return QMM_OK;
     }
     c->mfma_calls++;
-    int last_key = -1;                   // the group shares src1: its 16-bit operand is prepared once per activation format
+    // The group shares src1: its 16-bit operand is prepared once per activation format (key).  Runs of same-type matrices are one tiled
+    // launch each where the shapes allow (mfma_mul_mat_group).  A run with a NEW key has nothing in common with what was issued before
+    // it except src1: it goes to a side stream (own workspace slice) between a fork and a join event, so that its prep / MFMA / reduce
+    // launches overlap the earlier runs' instead of queueing behind them; a run that reuses a prep stays on that prep's stream.
+    struct Run { int i, j, key, lane; };
+    Run runs[MV_MAX_GROUP * 2];
+    int nruns = 0;
     for (int i = 0; i < nw;) {
         if (ws[i].M == 0) { ++i; continue; }
-        int j = i + 1;                   // run of same-type matrices: one tiled launch where the shapes allow (mfma_mul_mat_group)
+        int j = i + 1;
         while (j < nw && j - i < 4 && ws[j].type == ws[i].type && ws[j].M > 0) ++j;
         const int key = mfma_prep_key(c, ws[i].type, N, ws[i].M);
         bool same_key = true;
         for (int k = i + 1; k < j; ++k) same_key = same_key && mfma_prep_key(c, ws[k].type, N, ws[k].M) == key;
         if (!same_key) j = i + 1;
-        int rc = j - i > 1 ? mfma_mul_mat_group(c, st, ws[i].type, ws + i, j - i, K, x, N, ldx, key == last_key)
-                           : mfma_mul_mat(c, st, ws[i].type, ws[i].w, ws[i].w_row_bytes, K, ws[i].M, x, N, ldx, ws[i].dst, ws[i].ldd, key == last_key);
-        if (rc) return rc;
-        last_key = key;
+        if (nruns == (int) (sizeof(runs) / sizeof(runs[0]))) return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_group: too many runs in one group");
+        runs[nruns++] = { i, j, key, 0 };
         i = j;
     }
-    return QMM_OK;
+    int nlanes = 1;                                              // lane 0 = the caller's stream, 1..3 = side streams
+    const bool side = c->side_on && nruns > 1 && !c->prep_x2;
+    for (int r = 1; r < nruns; ++r) {
+        int found = -1;
+        for (int q = 0; q < r; ++q) if (runs[q].key == runs[r].key) found = runs[q].lane;      // reuses that run's prep: same stream, behind it
+        runs[r].lane = found >= 0 ? found : (side && nlanes < 4 ? nlanes++ : 0);
+    }
+    if (nlanes > 1) {
+        for (int l = 1; l < nlanes; ++l) {
+            if (!c->side[l - 1]) HIP_TRY(hipStreamCreateWithFlags(&c->side[l - 1], hipStreamNonBlocking));
+            if (!c->ev_join[l - 1]) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[l - 1], hipEventDisableTiming));
+        }
+        if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        for (int l = 1; l < nlanes; ++l) HIP_TRY(hipStreamWaitEvent(c->side[l - 1], c->ev_fork, 0));
+    }
+    // disjoint workspace slices, sized up front by what a lane's runs can take at most (operand + scales + 8 split-K slabs of its rows)
+    size_t lane_base[4] = { 0, 0, 0, 0 };
+    {
+        const size_t fixed = (size_t) mfma_npad(N) * mfma_kpad(K) * 2 + (((size_t) mfma_npad(N) * 4 + 255) & ~(size_t) 255) + 1024;
+        size_t rows[4] = { 0, 0, 0, 0 };
+        for (int r = 0; r < nruns; ++r)
+            for (int k = runs[r].i; k < runs[r].j; ++k) rows[runs[r].lane] += (size_t) ws[k].M;
+        size_t base = 0;
+        for (int l = 0; l < nlanes; ++l) { lane_base[l] = base; base += (fixed + 8 * (size_t) N * rows[l] * sizeof(float) + 255) & ~(size_t) 255; }
+        if (nlanes == 1) lane_base[0] = 0;
+    }
+    int lane_key[4] = { -1, -1, -1, -1 };
+    int rc = QMM_OK;
+    // side lanes first: their (small) launches are in the queues when the caller's stream starts on the big run
+    for (int pass = 0; pass < 2 && rc == QMM_OK; ++pass)
+        for (int r = 0; r < nruns && rc == QMM_OK; ++r) {
+            const Run & R = runs[r];
+            if ((pass == 0) != (R.lane != 0)) continue;
+            c->ws_base = lane_base[R.lane];
+            hipStream_t ls = R.lane ? c->side[R.lane - 1] : st;
+            const bool reuse = R.key == lane_key[R.lane];
+            rc = R.j - R.i > 1 ? mfma_mul_mat_group(c, ls, ws[R.i].type, ws + R.i, R.j - R.i, K, x, N, ldx, reuse)
+                               : mfma_mul_mat(c, ls, ws[R.i].type, ws[R.i].w, ws[R.i].w_row_bytes, K, ws[R.i].M, x, N, ldx, ws[R.i].dst, ws[R.i].ldd, reuse);
+            lane_key[R.lane] = R.key;
+        }
+    c->ws_base = 0;
+    for (int l = 1; l < nlanes; ++l) {                           // join on every path: a capture must not end with a dangling side stream
+        const hipError_t e1 = hipEventRecord(c->ev_join[l - 1], c->side[l - 1]);
+        const hipError_t e2 = hipStreamWaitEvent(st, c->ev_join[l - 1], 0);
+        if (rc == QMM_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(QMM_EHIP, "qmm_mul_mat_group: joining the side stream failed");
+    }
+    return rc;
 }
 
 // dst = W * (silu(gate) .* up) for a prompt batch: ffn_down with the SwiGLU product formed by the activation prep of the MFMA path

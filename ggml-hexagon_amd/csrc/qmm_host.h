@@ -30,6 +30,18 @@ struct qmm_ctx {
     // workspace of the batched path (16-bit activations, row scales, MoE lists); grown on demand
     void *      ws = nullptr;
     size_t      ws_bytes = 0;
+    size_t      ws_base = 0, ws_used = 0;   // prefill runs that are in flight together use disjoint slices: a run works at ws + ws_base and reports what it took
+    // Runs of a prefill group that need their own activation prep (another weight format: attn_v in Q6_K beside attn_q / attn_k in
+    // Q4_K) go out on side streams between a fork and a join event: their prep / MFMA / reduce launches, each too small to fill the
+    // chip, overlap the first run's instead of queueing behind them (GGML_MI355X_SIDE=0: one stream)
+    int         side_on = 0;             // (measured on llama3-8b q/k/v with attn_v in Q6_K: 74 us one stream, 78.5 us with the Q6_K run on a side stream: the two events cost more than the overlap wins)
+    hipStream_t side[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t  ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };
+    int         splitk_combine = 0;  // GGML_MI355X_SPLITK_COMBINE=1: split-K ranges combined inside the launch (splitk_finish_wave) instead of by splitk_reduce_kernel.
+                                     // Bit-identical, measured a wash on llama3-8b at 512 tokens (wo 46.1 -> 43.9 us, q/k/v 72.4 -> 73.0, ffn_down 105.5 -> 107.1): the
+                                     // slabs' traffic stays, and the last arriver's four dependent read trips cost what the reduce launch cost.  Opt-in.
+    int *       kcnt = nullptr;      // its arrival counters (zero between launches), one per (row tile, token tile, wave)
+    int64_t     kcnt_n = 0;
     int *       flag = nullptr;      // device word set by kernels that meet an expert id out of range
     const float * prep_x2 = nullptr; // transient: second operand of a SwiGLU input while qmm_mul_mat_swiglu_in runs (prefill prep)
     int64_t     prep_ldx2 = 0;

@@ -215,3 +215,94 @@ def test_r64_group_launch_equals_the_32_row_kernel(qmm_by_r64):
         for v in (1, 2, 3):
             for a, b in zip(outs[v], outs[0]):
                 assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (v, ms)
+
+
+def _contexts(env_name, values):
+    """one context per value of an environment switch that the library reads when a context is created"""
+    import os
+    from ggml_hexagon_amd.capi import Qmm
+    made, old = {}, os.environ.get(env_name)
+    try:
+        for v in values:
+            os.environ[env_name] = str(v)
+            made[v] = Qmm(0)
+    finally:
+        if old is None:
+            os.environ.pop(env_name, None)
+        else:
+            os.environ[env_name] = old
+    return made
+
+
+@pytest.fixture(scope="module")
+def qmm_by_combine():
+    made = _contexts("GGML_MI355X_SPLITK_COMBINE", (0, 1))          # (0 is the default: measured a wash, DESIGN.md)
+    yield made
+    for q in made.values():
+        q.close()
+
+
+@pytest.mark.parametrize("t,k,ms,n", [(Q4_K, 4096, (4096,), 512), (Q4_K, 4096, (4096, 1024, 1024), 512), (Q4_K, 14336, (4096,), 512),
+                                     (Q6_K, 14336, (4096,), 512), (Q6_K, 4096, (1024,), 512), (Q4_0, 4096, (4096,), 300), (Q5_K, 8192, (8192,), 129),
+                                     (Q8_0, 4096, (1000,), 512), (Q4_K, 4096, (4096, 1024), 200), (Q4_K, 2048, (2048,), 512)],
+                         ids=["wo", "qkv-group", "down", "down-q6k", "v-q6k", "q4_0-ragged-tokens", "q5k-70b", "q8_0-ragged-rows", "group-ragged", "k2048"])
+def test_splitk_combined_in_the_launch_equals_the_reduce_kernel(qmm_by_combine, oracle, t, k, ms, n):
+    """split-K with the ranges combined by the launch itself (splitk_finish_wave: write-through partial slabs, an arrival counter per
+    wave-sized unit, the last arriver adds the slabs in range order) gives the bits splitk_reduce_kernel gives, on single matrices and
+    group launches, ragged rows / tokens, 2-4 ranges; repeated, so that the counters' return to zero is exercised; one case against
+    the oracle on sampled rows.  The trace must show that the reduce kernel is gone where the combine applies."""
+    import ggml_hexagon_amd.synth as synth
+    dev = torch.device("cuda", 0)
+    ws = [synth.synth_weights_torch(t, m, k, dev, seed=31 + i + m) for i, m in enumerate(ms)]
+    x = torch.rand((n, k), device=dev, generator=torch.Generator(device=dev).manual_seed(n + k)) * 2 - 1
+    outs, labels = {}, {}
+    for v, q in qmm_by_combine.items():
+        o = [torch.full((n, m), float("nan"), device=dev) for m in ms]
+        labels[v] = q.trace(lambda: q.mul_mat_group([(t, w) for w in ws], k, x, o))
+        for _ in range(3):                                    # the same launches again: counters must have come back to zero
+            for oo in o:
+                oo.fill_(float("nan"))
+            q.mul_mat_group([(t, w) for w in ws], k, x, o)
+        q.synchronize()
+        outs[v] = o
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (t, k, ms, n, float((a - b).abs().max()))
+    # where the combine applies (256 x 128 tiles, <= 4 ranges) the reduce kernel must be gone; the named shapes are such cases
+    combined = [l for l in labels[1] if l.endswith("+combine")]
+    if (k, ms, n) in ((4096, (4096,), 512), (14336, (4096,), 512)):
+        assert combined and not any("splitk_reduce_kernel" in l for l in labels[1]), labels
+    if ms == (4096,) and t == Q4_K and k == 4096:
+        rng = np.random.default_rng(3)
+        rows, toks = np.sort(rng.choice(ms[0], 32, replace=False)), np.sort(rng.choice(n, 64, replace=False))
+        want = oracle.mul_mat(t, ws[0][torch.from_numpy(rows).to(dev)].cpu().numpy(), k, x.cpu().numpy()[toks], ACT_REF)
+        assert rel_l2(outs[1][0].cpu().numpy()[np.ix_(toks, rows)], want) <= 1e-3
+
+
+@pytest.fixture(scope="module")
+def qmm_by_r64s():
+    made = _contexts("GGML_MI355X_R64S", (0, 1))
+    yield made
+    for q in made.values():
+        q.close()
+
+
+@pytest.mark.parametrize("k,ms,n", [(4096, (14336, 14336), 512), (8192, (28672,), 512), (4096, (14336, 14336), 300), (4096, (28000,), 512), (512, (32768,), 512)],
+                         ids=["gate-up", "70b-gate", "ragged-tokens", "ragged-rows", "two-blocks"])
+def test_hand_placed_k_step_equals_the_compiler_scheduled_kernel(qmm_by_r64s, k, ms, n):
+    """mfma_r64s_q4k_kernel (csrc/qmm_mfma_r64s.hiph: the K-step's instruction stream placed by hand, the barrier between its third
+    and fourth k-step, headers requested twice in place) against mfma_r64_q4k_kernel<8>: the same MFMAs on the same fragments in the
+    same order, so the same bits; the trace shows which kernel ran"""
+    import ggml_hexagon_amd.synth as synth
+    dev = torch.device("cuda", 0)
+    ws = [synth.synth_weights_torch(Q4_K, m, k, dev, seed=77 + i) for i, m in enumerate(ms)]
+    x = torch.rand((n, k), device=dev, generator=torch.Generator(device=dev).manual_seed(n)) * 2 - 1
+    outs, labels = {}, {}
+    for v, q in qmm_by_r64s.items():
+        o = [torch.full((n, m), float("nan"), device=dev) for m in ms]
+        labels[v] = q.trace(lambda: q.mul_mat_group([(Q4_K, w) for w in ws], k, x, o))
+        q.synchronize()
+        outs[v] = o
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (k, ms, n, float((a - b).abs().max()))
+    if any(l.startswith("mfma_r64_q4k_kernel<8>") for l in labels[0]):
+        assert any(l.startswith("mfma_r64s_q4k_kernel") for l in labels[1]), labels

@@ -85,13 +85,15 @@ def test_partial_offload(gguf, ngl):
     assert r["worst_nmse"] < 5e-3, r
 
 
-@pytest.mark.parametrize("config,what,per_token", [("tiny-q4_k_m", "fused: rope + kv store + attention", 2), ("tiny-moe-q4_k_m", "fused: moe router", 2),
-                                                   ("tiny-moe-q4_k_m", "fused: rope + kv store + attention", 2)])
+@pytest.mark.parametrize("config,what,per_token", [("tiny-q4_k_m", "fused: rope + kv store + attention", 3), ("tiny-moe-q4_k_m", "fused: moe router", 1),
+                                                   ("tiny-moe-q4_k_m", "fused: rope + kv store + attention", 1)])
 def test_fusions_fire_in_llamas_own_graph_order(tmp_path, config, what, per_token):
     """the multi-node launches are matched against the graphs libllama really builds: `ggml_build_forward_expand` orders nodes
     depth-first (the router's get_rows / sum_rows / div land behind the expert MUL_MAT_IDs) and ggml-alloc places the merged heads
     across the dead Q blocks.  Both once kept a fusion from firing in every layer while all op-level tests passed (round 2), so the
-    debug log of a 2-layer model must name each launch once per layer and token."""
+    debug log of a 4- / 2-layer model must name each launch once per layer and token, the LAST layer excepted: nothing behind it
+    reuses its tensors' memory, so the module cannot prove that all their readers are in its split and computes them node by node
+    (round 3, csrc/ggml-mi355x.cpp analyze_readers; tests/cpp/test_cross_split.cpp)."""
     if not E2E.exists() or not PLUGIN.exists():
         pytest.skip("oracle/_ref/llama-e2e or the plugin module is not built (needs the reference tree at build time)")
     path = str(tmp_path / f"{config}.gguf")

@@ -106,3 +106,16 @@ def test_fusions_survive_forced_buffer_aliasing():
     assert not fails, "\n".join(fails[:20])
     m = re.search(r"(\d+) OK, (\d+) FAILED", out)
     assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) == 36, out[-3000:]
+
+
+def test_readers_in_another_scheduler_split_get_real_data():
+    """tests/cpp/test_cross_split.cpp: an op the device refuses sits inside a layer and reads a tensor a multi-node launch would have
+    skipped or sent to the scratch; through ggml_backend_sched over { MI355X, CPU } against the CPU alone"""
+    exe = ROOT / "oracle" / "_ref" / "test-cross-split"
+    if not exe.exists() or not PLUGIN.exists():
+        pytest.skip("oracle/_ref/test-cross-split or the plugin module is not built (needs the reference tree at build time)")
+    p = subprocess.run([str(exe)], env=dict(os.environ, GGML_BACKEND_PATH=str(PLUGIN)), capture_output=True, text=True, timeout=600, cwd=str(exe.parent))
+    out = p.stdout + p.stderr
+    import re
+    m = re.search(r"(\d+) OK, (\d+) FAILED", out)
+    assert p.returncode == 0 and m and int(m.group(2)) == 0 and int(m.group(1)) == 12, out[-3000:]

@@ -48,6 +48,12 @@ def test_graph_fuzzer_planning_is_sanitizer_clean(env):
     assert p.returncode == 0 and "40 OK, 0 FAILED" in p.stdout, (p.stdout + p.stderr)[-2000:]
 
 
+def test_cross_split_planning_is_sanitizer_clean(env):
+    p = subprocess.run([str(REF / "test-cross-split")], env=env, capture_output=True, text=True, timeout=600, cwd=str(REF))
+    clean(p.stdout + p.stderr)                      # (numbers cannot match on the stub; the scheduler must have made its splits)
+    assert "splits" in p.stdout and "FAILED" in p.stdout
+
+
 def test_planar_weight_bookkeeping_is_sanitizer_clean(env):
     p = subprocess.run([str(REF / "test-planar-weights")], env=env, capture_output=True, text=True, timeout=600, cwd=str(REF))
     clean(p.stdout + p.stderr)                      # its numeric checks cannot pass on the stub; only the sanitizers are asserted
