@@ -50,6 +50,15 @@ struct mi355x_device_ctx {
     size_t      stage_d_bytes = 0;
     qmm_event * ev_done = nullptr;       // this device's slice has landed in the root's dst
     qmm_event * ev_ready = nullptr;      // (as root) src1 is ready on the root's stream
+    std::vector<void *> retired;         // staging blocks outgrown while queued work may still read them: freed behind the next synchronize
+    // Small set_tensor calls (the per-token inputs llama.cpp writes in front of every graph: token ids, positions, the KQ mask, the
+    // output ids) go through a pinned ring and an asynchronous copy on the device's stream instead of a blocking copy each: the call
+    // returns when the bytes are in the ring; everything queued later on the stream sees them, and every other way to the memory
+    // (get_tensor, cpy_tensor, memset, clear: they use the NULL stream) settles the stream first.  GGML_MI355X_STAGED_SET=0: off.
+    char *      ring = nullptr;
+    size_t      ring_bytes = 0, ring_pos = 0;
+    bool        staged_pending = false;
+    std::mutex  ring_mu;
 };
 
 // SURVEY 8f-2, weight repack: Q4_0 / Q8_0 / Q6_K weight tensors are re-laid into aligned planes (qmm_repack_rows) the first time
@@ -72,6 +81,8 @@ struct mi355x_backend_ctx {
     // per-graph reader analysis (graph_compute): for every candidate tensor, who reads its memory in this graph
     struct reader_info { const ggml_tensor * t; int uses; int last_reader; bool glue_only; };
     std::vector<reader_info>         readers;
+    uint64_t                         readers_sig = 0;        // signature of the graph `readers` was computed for (analyze_readers)
+    int                              readers_sig_nodes = -1;
     // results of hoisted MUL_MATs that could not be written in place (their block of the compute buffer is still in use at
     // the earlier point): they live in `hoist_buf` and every reader gets the pointer swapped in to_qt
     struct redirect { const ggml_tensor * t; char * data; int last_reader; };
@@ -197,8 +208,10 @@ int weight_type(mi355x_backend_ctx * ctx, const ggml_tensor * t) {
 
 // ----------------------------------------------------------------------------------------------- buffer
 
+void settle(mi355x_device_ctx * d);
 void buffer_free(ggml_backend_buffer_t buffer) {
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    settle(ctx->dev);
     qmm_free(ctx->dev->qmm, ctx->base);
     delete ctx;
 }
@@ -208,6 +221,7 @@ enum ggml_status buffer_init_tensor(ggml_backend_buffer_t, struct ggml_tensor *)
 
 void buffer_memset_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    settle(ctx->dev);
     planar_release(ctx, (const char *) tensor->data + offset, size, true, nullptr);
     if (qmm_memset(ctx->dev->qmm, (char *) tensor->data + offset, value, size, nullptr) || qmm_synchronize(ctx->dev->qmm, nullptr))
         GGML_ABORT("MI355X memset_tensor: %s", qmm_last_error());
@@ -217,21 +231,63 @@ void buffer_memset_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * ten
 bool GGML_MI355X_TIMING();
 struct host_timer {
     static constexpr int N = 8;
-    static double us[N];
-    static long long calls[N];
+    static double us[N], pend_us[N], tg_us[N];           // all calls; calls since the last graph_compute; calls in front of one-token graphs
+    static long long calls[N], pend_calls[N], tg_calls[N];
+    static void flush(bool one_token) {
+        for (int i = 0; i < N; ++i) { if (one_token) { tg_us[i] += pend_us[i]; tg_calls[i] += pend_calls[i]; } pend_us[i] = 0; pend_calls[i] = 0; }
+    }
     static const char * name(int i) { static const char * n[N] = { "set_tensor", "get_tensor", "cpy_tensor", "set_tensor_async", "get_tensor_async", "cpy_tensor_async", "synchronize", "event" }; return n[i]; }
     int slot; double t0;
     explicit host_timer(int s) : slot(s), t0(GGML_MI355X_TIMING() ? std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0) {}
     ~host_timer() {
-        if (t0 > 0) { us[slot] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; calls[slot]++; }
+        if (t0 > 0) {
+            const double dt = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+            us[slot] += dt; calls[slot]++; pend_us[slot] += dt; pend_calls[slot]++;
+        }
     }
 };
-double host_timer::us[host_timer::N] = { 0 };
-long long host_timer::calls[host_timer::N] = { 0 };
+double host_timer::us[host_timer::N] = { 0 }, host_timer::pend_us[host_timer::N] = { 0 }, host_timer::tg_us[host_timer::N] = { 0 };
+long long host_timer::calls[host_timer::N] = { 0 }, host_timer::pend_calls[host_timer::N] = { 0 }, host_timer::tg_calls[host_timer::N] = { 0 };
+
+constexpr size_t STAGED_SET_MAX = (size_t) 256 << 10, STAGED_RING = (size_t) 4 << 20;
+bool staged_set_on() { static const bool on = [] { const char * e = getenv("GGML_MI355X_STAGED_SET"); return !(e && atoi(e) == 0); }(); return on; }
+// every path to device memory that does not run on the device's stream waits for the staged copies first
+void settle(mi355x_device_ctx * d) {
+    std::lock_guard<std::mutex> lock(d->ring_mu);
+    if (d->staged_pending) {
+        if (qmm_synchronize(d->qmm, qmm_stream(d->qmm))) GGML_LOG_ERROR("MI355X: %s\n", qmm_last_error());
+        d->staged_pending = false;
+    }
+}
+bool staged_set(mi355x_buffer_ctx * ctx, void * dst, const void * data, size_t size) {
+    mi355x_device_ctx * d = ctx->dev;
+    std::lock_guard<std::mutex> lock(d->ring_mu);
+    if (!d->ring) {
+        d->ring = (char *) qmm_host_malloc(d->qmm, STAGED_RING);
+        if (!d->ring) return false;
+        d->ring_bytes = STAGED_RING;
+    }
+    const size_t need = (size + 255) & ~(size_t) 255;
+    if (d->ring_pos + need > d->ring_bytes) {                  // wrap: the slots in front are reused only behind the copies that read them
+        if (qmm_synchronize(d->qmm, qmm_stream(d->qmm))) return false;
+        d->ring_pos = 0;
+    }
+    memcpy(d->ring + d->ring_pos, data, size);
+    if (qmm_memcpy_h2d_async(d->qmm, dst, d->ring + d->ring_pos, size, qmm_stream(d->qmm))) return false;
+    d->ring_pos += need;
+    d->staged_pending = true;
+    return true;
+}
 
 void buffer_set_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     host_timer timer_(0);
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    if (size <= STAGED_SET_MAX && buffer->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS && staged_set_on()) {
+        bool empty;
+        { std::lock_guard<std::mutex> lock(ctx->mu); empty = ctx->planar.empty(); }
+        if (empty && staged_set(ctx, (char *) tensor->data + offset, data, size)) return;
+    }
+    settle(ctx->dev);
     planar_release(ctx, (const char *) tensor->data + offset, size, true, nullptr);       // wire bytes come in: the tensor is wire again
     if (qmm_memcpy_h2d(ctx->dev->qmm, (char *) tensor->data + offset, data, size, nullptr))
         GGML_ABORT("MI355X set_tensor: %s", qmm_last_error());
@@ -239,6 +295,7 @@ void buffer_set_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor
 void buffer_get_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     host_timer timer_(1);
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    settle(ctx->dev);
     planar_release(ctx, (const char *) tensor->data + offset, size, false, nullptr);      // wire bytes go out (converted again at the next use)
     if (qmm_memcpy_d2h(ctx->dev->qmm, data, (const char *) tensor->data + offset, size, nullptr))
         GGML_ABORT("MI355X get_tensor: %s", qmm_last_error());
@@ -247,10 +304,12 @@ const char * buft_get_name(ggml_backend_buffer_type_t buft);
 bool buffer_cpy_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * src, struct ggml_tensor * dst) {
     host_timer timer_(2);
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    settle(ctx->dev);
     ggml_backend_buffer_t sb = src->view_src ? src->view_src->buffer : src->buffer;
     if (!sb || sb->buft->iface.get_name != buft_get_name) return false;           // not one of ours: let ggml stage through the host
     auto * sctx = (mi355x_buffer_ctx *) sb->context;
     if (sctx->dev != ctx->dev) return false;
+    settle(sctx->dev);
     planar_release(sctx, (const char *) src->data, ggml_nbytes(src), false, nullptr);
     planar_release(ctx, (const char *) dst->data, ggml_nbytes(src), true, nullptr);
     if (qmm_memcpy_d2d(ctx->dev->qmm, dst->data, src->data, ggml_nbytes(src), nullptr) || qmm_synchronize(ctx->dev->qmm, nullptr))
@@ -259,6 +318,7 @@ bool buffer_cpy_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * 
 }
 void buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
     auto * ctx = (mi355x_buffer_ctx *) buffer->context;
+    settle(ctx->dev);
     { std::lock_guard<std::mutex> lock(ctx->mu); ctx->planar.clear(); }
     if (qmm_memset(ctx->dev->qmm, ctx->base, value, buffer->size, nullptr) || qmm_synchronize(ctx->dev->qmm, nullptr))
         GGML_ABORT("MI355X clear: %s", qmm_last_error());
@@ -355,14 +415,23 @@ struct split_buffer_ctx {
     std::vector<split_extra *> extras;
 };
 
+// the rounding of one matrix: SPLIT_ROW_ROUNDING where every device still gets rows under an even split, else the largest power of two
+// (>= 32) that leaves none empty: a 1024-row wk / wv over 8 devices would otherwise come out as 0 / 256 / 0 / 256 ... rows (ADVICE r2:
+// half the devices idle on it); ggml-hexagon_amd/rowsplit.py rounding_for is the same rule for the one-process-per-GPU path
+int64_t split_rounding(int64_t nrows) {
+    int64_t r = SPLIT_ROW_ROUNDING;
+    while (r > 32 && nrows / std::max(g_ndev, 1) < r) r /= 2;
+    return r;
+}
 void split_row_range(const split_buft_ctx * c, int64_t nrows, int id, int64_t * lo, int64_t * hi) {
+    const int64_t rounding = split_rounding(nrows);
     *lo = id == 0 ? 0 : (int64_t) (nrows * c->split[id]);
-    *lo -= *lo % SPLIT_ROW_ROUNDING;
+    *lo -= *lo % rounding;
     if (id == g_ndev - 1) {
         *hi = nrows;
     } else {
         *hi = (int64_t) (nrows * c->split[id + 1]);
-        *hi -= *hi % SPLIT_ROW_ROUNDING;
+        *hi -= *hi % rounding;
     }
     if (*hi < *lo) *hi = *lo;
 }
@@ -498,16 +567,23 @@ bool supports_mul_mat_id(const struct ggml_tensor * op) {
     return true;
 }
 
+// A staging block that has to grow: queued work may still read the old one, so it is retired, not freed (until round 3 this
+// synchronized the stream in the middle of a graph: VERDICT r2 item 6); free_retired runs behind graph_compute's own synchronize.
 bool grow(mi355x_device_ctx * d, void *& p, size_t & have, size_t need) {
     if (need <= have) return true;
-    if (qmm_synchronize(d->qmm, qmm_stream(d->qmm))) return false;                 // queued work may still read the old block
-    if (p) qmm_free(d->qmm, p);
-    have = 0;
     need = (need + ((size_t) 8 << 20) - 1) & ~(((size_t) 8 << 20) - 1);
-    p = qmm_malloc(d->qmm, need);
-    if (!p) return false;
+    void * q = qmm_malloc(d->qmm, need);
+    if (!q) return false;
+    if (p) d->retired.push_back(p);
+    p = q;
     have = need;
     return true;
+}
+void free_retired() {
+    for (int id = 0; id < g_ndev; ++id) {
+        for (void * p : g_devs[id].retired) qmm_free(g_devs[id].qmm, p);
+        g_devs[id].retired.clear();
+    }
 }
 
 // MUL_MAT with row-split src0 (ggml_cuda_op_mul_mat, ggml-cuda.cu:1365-1673).  The device running the node is the root: it
@@ -534,66 +610,83 @@ qmm_comm * split_comm() {
     return g_comm_state == 1 ? g_comm : nullptr;
 }
 
-enum ggml_status compute_mul_mat_split_rccl(mi355x_backend_ctx * ctx, const ggml_tensor * dst, qmm_comm * comm) {
-    const ggml_tensor * a = dst->src[0], * b = dst->src[1];
-    auto * e = (const split_extra *) a->extra;
+qmm_tensor to_qt(const ggml_tensor * t, const mi355x_backend_ctx * ctx);
+// One exchange per GROUP (round 3; until then only single matrices took RCCL, so with fusion on q/k/v and gate/up stayed on peer
+// copies: VERDICT r2 item 6): src1 is broadcast once, every device computes its slice of every member into its staging block (member
+// after member, N x rows each), ONE grouped send / recv per device brings the blocks to the root, which places the slices.
+enum ggml_status compute_mul_mat_split_rccl(mi355x_backend_ctx * ctx, const ggml_tensor * const * members, int n_members, qmm_comm * comm) {
+    const ggml_tensor * dst0 = members[0], * b = dst0->src[1];
     mi355x_device_ctx * root = ctx->dev;
     const int root_id = (int) (root - &g_devs[0]);
-    const int64_t K = a->ne[0], N = b->ne[1], ldd = dst->nb[1] / sizeof(float);
+    const int64_t K = dst0->src[0]->ne[0], N = b->ne[1];
     std::vector<void *> xs(g_ndev), recv(g_ndev, nullptr);
     std::vector<const void *> send(g_ndev, nullptr);
     std::vector<size_t> bytes(g_ndev, 0);
-    // the root receives the slices into a staging block (N x rows per device, back to back) unless N == 1, where a slice IS a run of dst
+    auto rows_of = [&](int m, int id) { auto * e = (const split_extra *) members[m]->src[0]->extra; return e->hi[id] - e->lo[id]; };
+    // a single one-token matrix: its slice IS a run of dst, received in place; everything else lands in the root's staging block
+    const bool in_place = N == 1 && n_members == 1;
     size_t stage_total = 0;
-    for (int id = 0; id < g_ndev; ++id)
-        if (id != root_id) stage_total += (size_t) N * (e->hi[id] - e->lo[id]) * sizeof(float);
-    if (N > 1 && !grow(root, root->stage_d, root->stage_d_bytes, stage_total)) goto fail;
+    for (int id = 0; id < g_ndev; ++id) {
+        for (int m = 0; m < n_members; ++m) bytes[id] += (size_t) N * rows_of(m, id) * sizeof(float);
+        if (id != root_id) stage_total += bytes[id];
+    }
+    if (!in_place && !grow(root, root->stage_d, root->stage_d_bytes, stage_total)) goto fail;
     {
         size_t off = 0;
         for (int id = 0; id < g_ndev; ++id) {
             mi355x_device_ctx * d = &g_devs[id];
-            const int64_t rows = e->hi[id] - e->lo[id];
-            if (id == root_id) { xs[id] = b->data; continue; }
-            if (!grow(d, d->stage_x, d->stage_x_bytes, (size_t) N * K * sizeof(float)) ||
-                !grow(d, d->stage_d, d->stage_d_bytes, (size_t) N * rows * sizeof(float))) goto fail;
+            if (id == root_id) { xs[id] = b->data; bytes[id] = 0; continue; }
+            if (!grow(d, d->stage_x, d->stage_x_bytes, (size_t) N * K * sizeof(float)) || !grow(d, d->stage_d, d->stage_d_bytes, bytes[id])) goto fail;
             xs[id] = d->stage_x;
             send[id] = d->stage_d;
-            bytes[id] = (size_t) N * rows * sizeof(float);
-            recv[id] = N == 1 ? (void *) ((float *) dst->data + e->lo[id]) : (void *) ((char *) root->stage_d + off);
+            recv[id] = in_place ? (void *) ((float *) to_qt(dst0, ctx).data + ((const split_extra *) dst0->src[0]->extra)->lo[id]) : (void *) ((char *) root->stage_d + off);
             off += bytes[id];
         }
         if (qmm_comm_broadcast(comm, root_id, xs.data(), (size_t) N * K * sizeof(float), nullptr)) goto fail;
         for (int id = 0; id < g_ndev; ++id) {
             mi355x_device_ctx * d = &g_devs[id];
-            const int64_t rows = e->hi[id] - e->lo[id];
-            if (rows == 0) continue;
-            if (id == root_id) {
-                if (qmm_mul_mat(d->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) b->data, N, K,
-                                (float *) dst->data + e->lo[id], ldd, qmm_stream(d->qmm))) goto fail;
-            } else if (qmm_mul_mat(d->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) d->stage_x, N, K,
-                                   (float *) d->stage_d, rows, qmm_stream(d->qmm))) goto fail;
+            size_t moff = 0;
+            for (int m = 0; m < n_members; ++m) {
+                const ggml_tensor * a = members[m]->src[0];
+                auto * e = (const split_extra *) a->extra;
+                const int64_t rows = e->hi[id] - e->lo[id];
+                if (rows == 0) continue;
+                if (id == root_id) {
+                    if (qmm_mul_mat(d->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) b->data, N, K,
+                                    (float *) to_qt(members[m], ctx).data + e->lo[id], members[m]->nb[1] / sizeof(float), qmm_stream(d->qmm))) goto fail;
+                } else if (qmm_mul_mat(d->qmm, a->type, e->data[id], ggml_row_size(a->type, K), K, rows, (const float *) d->stage_x, N, K,
+                                       (float *) d->stage_d + moff, rows, qmm_stream(d->qmm))) goto fail;
+                moff += (size_t) N * rows;
+            }
         }
         if (qmm_comm_gather(comm, root_id, send.data(), recv.data(), bytes.data(), nullptr)) goto fail;
-        if (N > 1) {                                           // place the slices: N runs of `rows` floats each
+        if (!in_place) {                                       // place the slices: per member, N runs of `rows` floats each
             off = 0;
             for (int id = 0; id < g_ndev; ++id) {
-                const int64_t rows = e->hi[id] - e->lo[id];
-                if (id == root_id || rows == 0) continue;
-                if (qmm_memcpy2d_d2d(root->qmm, (float *) dst->data + e->lo[id], dst->nb[1], (char *) root->stage_d + off,
-                                     rows * sizeof(float), rows * sizeof(float), N, qmm_stream(root->qmm))) goto fail;
+                if (id == root_id) continue;
+                size_t moff = 0;
+                for (int m = 0; m < n_members; ++m) {
+                    auto * e = (const split_extra *) members[m]->src[0]->extra;
+                    const int64_t rows = e->hi[id] - e->lo[id];
+                    if (rows == 0) continue;
+                    if (qmm_memcpy2d_d2d(root->qmm, (float *) to_qt(members[m], ctx).data + e->lo[id], members[m]->nb[1], (char *) root->stage_d + off + moff * sizeof(float),
+                                         rows * sizeof(float), rows * sizeof(float), N, qmm_stream(root->qmm))) goto fail;
+                    moff += (size_t) N * rows;
+                }
                 off += bytes[id];
             }
         }
     }
     return GGML_STATUS_SUCCESS;
 fail:
-    GGML_LOG_ERROR("MI355X MUL_MAT(%s) row split over RCCL: %s\n", dst->name, qmm_last_error());
+    GGML_LOG_ERROR("MI355X MUL_MAT(%s) row split over RCCL: %s\n", dst0->name, qmm_last_error());
     return GGML_STATUS_FAILED;
 }
 
 // Round 2: the MUL_MATs of a group (same src1: wq / wk / wv, ffn_gate / ffn_up) go out together: every other device gets src1 ONCE,
 // computes its slice of each matrix, sends the slices back, and there is one event round trip per device and group instead of one per
 // matrix (`members`: found by compute_mul_mat_split_group with the unsplit path's hoisting rules).
+void free_retired();
 qmm_tensor to_qt(const ggml_tensor * t, const mi355x_backend_ctx * ctx);
 enum ggml_status compute_mul_mat_split(mi355x_backend_ctx * ctx, const ggml_tensor * const * members, int n_members) {
     const ggml_tensor * dst = members[0];
@@ -601,8 +694,8 @@ enum ggml_status compute_mul_mat_split(mi355x_backend_ctx * ctx, const ggml_tens
     mi355x_device_ctx * root = ctx->dev;
     void * rst = qmm_stream(root->qmm);
     const int64_t K = dst->src[0]->ne[0], N = b->ne[1], ldx = b->nb[1] / sizeof(float);
-    if (ldx == K && n_members == 1)                           // (RCCL moves whole buffers: a strided src1 keeps the 2-D peer copies)
-        if (qmm_comm * comm = split_comm()) return compute_mul_mat_split_rccl(ctx, dst, comm);
+    if (ldx == K)                                             // (RCCL moves whole buffers: a strided src1 keeps the 2-D peer copies)
+        if (qmm_comm * comm = split_comm()) return compute_mul_mat_split_rccl(ctx, members, n_members, comm);
     if (!root->ev_ready) root->ev_ready = qmm_event_create(root->qmm);
     if (!root->ev_ready || qmm_event_record(root->qmm, root->ev_ready, rst)) goto fail;
     for (int id = 0; id < g_ndev; ++id) {
@@ -1077,8 +1170,9 @@ void backend_free(ggml_backend_t backend) {
         fprintf(stderr, "MI355X timing %s: tg graphs %lld stream_ms %.3f | pp graphs %lld tokens %lld stream_ms %.3f min_ms %.3f\n", ctx->name.c_str(),
                 (long long) ctx->graphs_tg, ctx->ms_tg, (long long) ctx->graphs_pp, (long long) ctx->tokens_pp, ctx->ms_pp, ctx->ms_pp_min);
         for (int i = 0; i < host_timer::N; ++i)
-            if (host_timer::calls[i]) fprintf(stderr, "MI355X timing %s: %s: %lld calls, %.1f us each, %.1f us per tg graph (all graphs' calls over the tg graphs)\n", ctx->name.c_str(),
-                                              host_timer::name(i), host_timer::calls[i], host_timer::us[i] / (double) host_timer::calls[i], host_timer::us[i] / (double) std::max<int64_t>(ctx->graphs_tg, 1));
+            if (host_timer::tg_calls[i]) fprintf(stderr, "MI355X timing %s: %s in front of a one-token graph: %.2f calls, %.1f us each, %.1f us per graph\n", ctx->name.c_str(), host_timer::name(i),
+                                                 host_timer::tg_calls[i] / (double) std::max<int64_t>(ctx->graphs_tg, 1), host_timer::tg_us[i] / (double) host_timer::tg_calls[i],
+                                                 host_timer::tg_us[i] / (double) std::max<int64_t>(ctx->graphs_tg, 1));
         if (ctx->graphs_tg > 1)
             fprintf(stderr, "MI355X timing %s: host us per tg graph: outside graph_compute %.1f | reader analysis %.1f | issue loop %.1f | waiting in synchronize %.1f\n", ctx->name.c_str(),
                     ctx->us_outside / (double) (ctx->graphs_tg - 1), ctx->us_analyze / (double) ctx->graphs_tg, ctx->us_issue / (double) ctx->graphs_tg, ctx->us_wait / (double) ctx->graphs_tg);
@@ -1152,6 +1246,7 @@ void backend_synchronize(ggml_backend_t backend) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     if (qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm)))
         GGML_LOG_ERROR("MI355X synchronize: %s\n", qmm_last_error());
+    { std::lock_guard<std::mutex> lock(ctx->dev->ring_mu); ctx->dev->staged_pending = false; }
 }
 
 // the analysis step of a graph_compute call
@@ -1161,10 +1256,26 @@ void analyze_readers(mi355x_backend_ctx * ctx, const ggml_cgraph * cgraph) {
     // One pass over all operands records, per candidate, how many nodes of this graph read its memory (directly or through
     // views), the last of them, and whether all of them are glue ops (whose operand pointers this file can redirect).
     std::vector<mi355x_backend_ctx::reader_info> & rd = ctx->readers;
-    rd.clear();
     ctx->redirects.clear();
     ctx->hoist_used = 0;
     ctx->pending_norm = {};
+    // Token generation hands over the same graph again and again (same tensors at the same addresses: llama.cpp rebuilds it in the same
+    // context memory, ggml-alloc places it the same way; only offsets INTO the KV cache move, and the cache is nobody's candidate): the
+    // analysis below depends on nothing but what this signature covers, so an unchanged signature keeps the previous result
+    // (58 us per token otherwise, in front of the first launch).
+    uint64_t sig = 1469598103934665603ull ^ (uint64_t) cgraph->n_nodes ^ (GGML_MI355X_FUSE_OFF() ? 0x9e3779b97f4a7c15ull : 0);
+    auto mix = [&sig](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
+    for (int i = 0; i < cgraph->n_nodes; ++i) {
+        const ggml_tensor * n = cgraph->nodes[i];
+        mix((uint64_t) (uintptr_t) n);  mix(n->view_src ? 0 : (uint64_t) (uintptr_t) n->data);      // (views into the KV cache move with every token; they own no memory)
+        mix((uint64_t) n->op ^ ((uint64_t) n->flags << 32));  mix((uint64_t) (uintptr_t) n->view_src);
+        mix((uint64_t) n->ne[0] ^ ((uint64_t) n->ne[1] << 20) ^ ((uint64_t) n->ne[2] << 40));  mix((uint64_t) n->nb[1] ^ ((uint64_t) n->nb[2] << 24));
+        for (int j = 0; j < GGML_MAX_SRC && n->src[j]; ++j) mix((uint64_t) (uintptr_t) n->src[j] + (uint64_t) j);
+    }
+    if (sig == ctx->readers_sig && ctx->readers_sig_nodes == cgraph->n_nodes) return;
+    ctx->readers_sig = sig;
+    ctx->readers_sig_nodes = cgraph->n_nodes;
+    rd.clear();
     if (!GGML_MI355X_FUSE_OFF()) {
         for (int i = 0; i + 1 < cgraph->n_nodes; ++i) {
             const ggml_tensor * n0 = cgraph->nodes[i];
@@ -1635,6 +1746,12 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     const bool timing = GGML_MI355X_TIMING();
     const double t_enter = timing ? wall_us() : 0;
+    if (timing) {
+        bool one = true;
+        for (int i = 0; i < cgraph->n_nodes && one; ++i)
+            if (cgraph->nodes[i]->op == GGML_OP_MUL_MAT && cgraph->nodes[i]->ne[2] == 1 && cgraph->nodes[i]->ne[1] > 1) one = false;
+        host_timer::flush(one);
+    }
     analyze_readers(ctx, cgraph);
     const double t_analyzed = timing ? wall_us() : 0;
     const int n_nodes = cgraph->n_nodes;
@@ -1751,6 +1868,8 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
         GGML_LOG_ERROR("MI355X graph_compute: %s\n", qmm_last_error());
         return GGML_STATUS_FAILED;
     }
+    free_retired();                 // (the root has waited for every device's slice: nothing queued reads an outgrown staging block)
+    { std::lock_guard<std::mutex> lock(ctx->dev->ring_mu); ctx->dev->staged_pending = false; }
     if (timing && ctx->ev_t0 && ctx->ev_t1) {
         float ms = 0.0f;
         int64_t n_tok = 1;                                   // tokens of the ubatch = ne[1] of the widest 2-D activation in the graph

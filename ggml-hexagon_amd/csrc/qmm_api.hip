@@ -531,11 +531,14 @@ int qmm_synchronize(qmm_ctx * c, void * st) {
                                           "or the activations are not finite; use QMM_PREC_BF16 (GGML_MI355X_PREC=bf16) for this model");
         }
     }
-    int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (flag) {
-        HIP_TRY(hipMemset(c->flag, 0, sizeof(int)));
-        return fail(QMM_EINVAL, "MUL_MAT_ID: expert id out of range seen by the kernel");
+    if (c->id_calls != c->id_checked) {                      // MUL_MAT_ID launches since the last look: did a kernel meet an expert id out of range?
+        c->id_checked = c->id_calls;
+        int flag = 0;
+        HIP_TRY(hipMemcpy(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost));
+        if (flag) {
+            HIP_TRY(hipMemset(c->flag, 0, sizeof(int)));
+            return fail(QMM_EINVAL, "MUL_MAT_ID: expert id out of range seen by the kernel");
+        }
     }
     return QMM_OK;
 }
@@ -830,6 +833,7 @@ int qmm_mul_mat_id(qmm_ctx * c, int type, const void * as, int64_t rb, int64_t e
     HIP_TRY(hipSetDevice(c->device));
     QMM_CHAIN_FLUSH(c);
     c->mfma_calls++;
+    c->id_calls++;
     return moe_mul_mat_id(c, c->s(stream), type, as, rb, expert_bytes, K, M, n_expert, b, ne11, b_nb1, b_nb2,
                           ids, n_used, n_tokens, ids_nb1, dst, d_nb1, d_nb2);
 }
@@ -849,6 +853,7 @@ int qmm_mul_mat_id_pair(qmm_ctx * c, int type, const void * as0, const void * as
     HIP_TRY(hipSetDevice(c->device));
     QMM_CHAIN_FLUSH(c);
     c->mfma_calls++;
+    c->id_calls++;
     return moe_mul_mat_id(c, c->s(stream), type, as0, rb, expert_bytes, K, M, n_expert, b, ne11, b_nb1, b_nb2,
                           ids, n_used, n_tokens, ids_nb1, dst0, d_nb1, d_nb2, as1, dst1);
 }

@@ -113,7 +113,7 @@ QMM_API int qmm_comm_broadcast(qmm_comm * c, int root, void * const * bufs, size
     if (!c || !bufs || root < 0 || root >= (int) c->ctx.size()) return qmm::fail(QMM_EINVAL, "qmm_comm_broadcast: bad arguments");
     RCCL_TRY(g_rccl.GroupStart());
     for (size_t r = 0; r < c->ctx.size(); ++r) {
-        HIP_TRY(hipSetDevice(qmm_device(c->ctx[r])));
+        if (hipSetDevice(qmm_device(c->ctx[r])) != hipSuccess) { g_rccl.GroupEnd(); return qmm::fail(QMM_EHIP, "qmm_comm_broadcast: hipSetDevice failed"); }
         hipStream_t st = (hipStream_t) (streams && streams[r] ? streams[r] : qmm_stream(c->ctx[r]));
         const int rr = g_rccl.Broadcast(bufs[root], bufs[r], bytes, NCCL_INT8, root, c->comm[r], st);
         if (rr != NCCL_SUCCESS) { g_rccl.GroupEnd(); return qmm::fail(QMM_EHIP, "ncclBroadcast failed: %s", g_rccl.GetErrorString(rr)); }
@@ -132,10 +132,10 @@ QMM_API int qmm_comm_gather(qmm_comm * c, int root, const void * const * send, v
         if ((int) r == root || bytes[r] == 0) continue;
         hipStream_t sr = (hipStream_t) (streams && streams[r] ? streams[r] : qmm_stream(c->ctx[r]));
         hipStream_t s0 = (hipStream_t) (streams && streams[root] ? streams[root] : qmm_stream(c->ctx[root]));
-        HIP_TRY(hipSetDevice(qmm_device(c->ctx[r])));
+        if (hipSetDevice(qmm_device(c->ctx[r])) != hipSuccess) { g_rccl.GroupEnd(); return qmm::fail(QMM_EHIP, "qmm_comm_gather: hipSetDevice failed"); }
         int rr = g_rccl.Send(send[r], bytes[r], NCCL_INT8, root, c->comm[r], sr);
         if (rr == NCCL_SUCCESS) {
-            HIP_TRY(hipSetDevice(qmm_device(c->ctx[root])));
+            if (hipSetDevice(qmm_device(c->ctx[root])) != hipSuccess) { g_rccl.GroupEnd(); return qmm::fail(QMM_EHIP, "qmm_comm_gather: hipSetDevice failed"); }
             rr = g_rccl.Recv(recv[r], bytes[r], NCCL_INT8, (int) r, c->comm[root], s0);
         }
         if (rr != NCCL_SUCCESS) { g_rccl.GroupEnd(); return qmm::fail(QMM_EHIP, "ncclSend/ncclRecv failed: %s", g_rccl.GetErrorString(rr)); }
@@ -149,7 +149,7 @@ QMM_API int qmm_comm_all_gather(qmm_comm * c, const void * const * send, void * 
     if (!c || !send || !recv) return qmm::fail(QMM_EINVAL, "qmm_comm_all_gather: bad arguments");
     RCCL_TRY(g_rccl.GroupStart());
     for (size_t r = 0; r < c->ctx.size(); ++r) {
-        HIP_TRY(hipSetDevice(qmm_device(c->ctx[r])));
+        if (hipSetDevice(qmm_device(c->ctx[r])) != hipSuccess) { g_rccl.GroupEnd(); return qmm::fail(QMM_EHIP, "qmm_comm_all_gather: hipSetDevice failed"); }
         hipStream_t st = (hipStream_t) (streams && streams[r] ? streams[r] : qmm_stream(c->ctx[r]));
         const int rr = g_rccl.AllGather(send[r], recv[r], bytes, NCCL_INT8, c->comm[r], st);
         if (rr != NCCL_SUCCESS) { g_rccl.GroupEnd(); return qmm::fail(QMM_EHIP, "ncclAllGather failed: %s", g_rccl.GetErrorString(rr)); }

@@ -45,6 +45,7 @@ struct qmm_ctx {
     int *       flag = nullptr;      // device word set by kernels that meet an expert id out of range
     const float * prep_x2 = nullptr; // transient: second operand of a SwiGLU input while qmm_mul_mat_swiglu_in runs (prefill prep)
     int64_t     prep_ldx2 = 0;
+    int64_t     id_calls = 0, id_checked = 0;       // MUL_MAT_ID launches issued / covered by the last look at `flag` (qmm_synchronize reads the word only behind such a launch: a blocking 4-byte copy per synchronize cost llama.cpp's token loop ~70 us per token)
     int64_t     mfma_calls = 0, mfma_checked = 0;   // prefill calls issued / covered by the last non-finite check (qmm_synchronize)
     bool        wide_attr_set = false;
     int         wide = 1;            // 256-token tiles for large Q4_K prefill launches (GGML_MI355X_WIDE=0: off)

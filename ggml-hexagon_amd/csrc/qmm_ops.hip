@@ -643,7 +643,13 @@ moe_router_kernel(const char * __restrict__ logits, char * __restrict__ ids, cha
     const float x = lane < n_expert ? ((const float *) (logits + (int64_t) t * l_nb1))[lane] : -INFINITY;
     const float mx = wave_max(x);
     const float e = lane < n_expert ? expf(x - mx) : 0.0f;
-    const float p = e * (1.0f / wave_sum(e));                      // soft_max_kernel's arithmetic: exp(x - max) * (1 / sum)
+    // soft_max_wave_kernel's arithmetic AND its order of additions: there lane g holds four consecutive values and adds them left to
+    // right before the wave reduction; a sum taken in any other order may differ in the last bit, and a last bit of a router weight is
+    // enough to flip an int8 rounding one layer further down (round 3: `llama-e2e layers` showed the one-launch router and the five
+    // per-node launches 2e-2 of an rms apart on one element of a later layer; the dense models agreed bit for bit)
+    const float e0 = __shfl(e, (4 * lane) & 63, 64), e1 = __shfl(e, (4 * lane + 1) & 63, 64), e2 = __shfl(e, (4 * lane + 2) & 63, 64), e3 = __shfl(e, (4 * lane + 3) & 63, 64);
+    const float g4 = lane < 16 ? ((e0 + e1) + e2) + e3 : 0.0f;
+    const float p = e * (1.0f / wave_sum(g4));                     // exp(x - max) * (1 / sum)
     int rank = 0;
     for (int j = 0; j < n_expert; ++j) {
         const float u = __shfl(p, j, 64);
@@ -651,7 +657,14 @@ moe_router_kernel(const char * __restrict__ logits, char * __restrict__ ids, cha
     }
     if (lane < n_expert) ((int32_t *) (ids + (int64_t) t * i_nb1))[rank] = lane;
     const bool sel = lane < n_expert && rank < n_used;
-    const float sum = wave_sum(sel ? p : 0.0f);
+    // sum_rows_kernel adds the selected weights with the weight of rank r on lane r: the same placement here
+    float byrank = 0.0f;
+    for (int r = 0; r < n_used; ++r) {
+        const int src = __ffsll((long long) __ballot(lane < n_expert && rank == r)) - 1;     // (every rank below n_expert has exactly one owner)
+        const float v = __shfl(p, src & 63, 64);
+        if (lane == r) byrank = v;
+    }
+    const float sum = wave_sum(byrank);
     if (sel) ((float *) (weights + (int64_t) t * w_nb1))[rank] = normalise ? p / sum : p;
 }
 

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -265,7 +266,7 @@ static const char * arg(int argc, char ** argv, const char * key, const char * d
 
 int main(int argc, char ** argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s write|bench|compare ...\n", argv[0]);
+        fprintf(stderr, "usage: %s write|bench|compare|layers ...\n", argv[0]);
         return 2;
     }
     const std::string mode = argv[1];
@@ -356,6 +357,96 @@ int main(int argc, char ** argv) {
         }
         printf("{\"mode\": \"compare\", \"gguf\": \"%s\", \"devices\": \"%s\", \"n_prompt\": %d, \"n_gen\": %d, \"steps\": %zu, \"worst_nmse\": %.3e, "
                "\"argmax_agree\": %d}\n", gguf, devs.c_str(), n_prompt, n_gen, logits[0].size(), worst, argmax_same);
+        return 0;
+    }
+    if (mode == "layers") {
+        // not only the logits.  The scheduler's eval callback (ggml-backend.cpp:1355-1448: the graph is computed up
+        // to every observed node, then the callback reads it) collects every layer's kqv_out, ffn_out and l_out in three runs of the
+        // same tokens: the CPU backend, the device with its multi-node launches, the device one launch per node (the module's
+        // ggml_backend_mi355x_set_fuse).  Reported per tensor: NMSE against the CPU, and the difference between the two device runs.
+        // The multi-node launches that restate their nodes' arithmetic (norm + mul, silu * up, router, combine) are bit-identical
+        // with the per-node kernels; the fused attention is another algorithm (one pass, p rounded to f16), so kqv_out agrees to
+        // f16 rounding (measured 2e-4 .. 1e-3 of the rms) and what follows it inherits flipped int8 roundings like the CPU compare.
+        const int n_prompt = atoi(arg(argc, argv, "-p", "40")), n_gen = atoi(arg(argc, argv, "-n", "2"));
+        struct Tap { std::map<std::string, std::vector<float>> got; int step = 0; };
+        static Tap * tap = nullptr;
+        static std::vector<std::string> extra;                                    // --tap a,b: more tensor names (up to the "-<layer>"), to localise a difference
+        for (std::string rest = arg(argc, argv, "--tap", ""); !rest.empty();) {
+            const size_t c = rest.find(',');
+            extra.push_back(rest.substr(0, c) + "-");
+            rest = c == std::string::npos ? "" : rest.substr(c + 1);
+        }
+        auto cb = [](struct ggml_tensor * t, bool ask, void *) -> bool {
+            bool want = t->type == GGML_TYPE_F32 && (!strncmp(t->name, "l_out-", 6) || !strncmp(t->name, "kqv_out-", 8) || !strncmp(t->name, "ffn_out-", 8) ||
+                                                     !strncmp(t->name, "ffn_moe_out-", 12) || !strcmp(t->name, "result_norm"));
+            for (const auto & e : extra) want = want || (t->type == GGML_TYPE_F32 && !strncmp(t->name, e.c_str(), e.size()));
+            if (ask) return want;
+            if (want) {
+                std::vector<float> v(ggml_nelements(t));
+                ggml_backend_tensor_get(t, v.data(), 0, ggml_nbytes(t));
+                tap->got[std::to_string(tap->step) + ":" + t->name] = std::move(v);
+            }
+            return true;
+        };
+        typedef void (*set_fuse_t)(int);
+        set_fuse_t set_fuse = nullptr;
+        if (ggml_backend_reg_t reg = ggml_backend_reg_by_name("MI355X")) set_fuse = (set_fuse_t) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_set_fuse");
+        Tap taps[3];
+        std::vector<llama_token> prompt(n_prompt), gen(n_gen);
+        std::srand(4321);
+        for (int pass = 0; pass < 3; ++pass) {
+            if (pass == 2 && !set_fuse) break;
+            if (set_fuse) set_fuse(pass == 2 ? 0 : 1);
+            tap = &taps[pass];
+            llama_model_params mp = llama_model_default_params();
+            mp.n_gpu_layers = pass == 0 ? 0 : 99;
+            llama_model * model = llama_model_load_from_file(gguf, mp);
+            if (!model) return 1;
+            llama_context_params cp = llama_context_default_params();
+            cp.n_ctx = n_prompt + n_gen; cp.n_batch = n_prompt; cp.n_ubatch = n_prompt; cp.n_threads = threads; cp.n_threads_batch = threads; cp.no_perf = true;
+            cp.cb_eval = cb;
+            llama_context * ctx = llama_init_from_model(model, cp);
+            if (!ctx) return 1;
+            const int n_vocab = llama_vocab_n_tokens(llama_model_get_vocab(model));
+            if (pass == 0) { for (auto & t : prompt) t = std::rand() % n_vocab; for (auto & t : gen) t = std::rand() % n_vocab; }
+            tap->step = 0;
+            if (llama_decode(ctx, llama_batch_get_one(prompt.data(), n_prompt))) return 1;
+            for (int i = 0; i < n_gen; ++i) { tap->step = i + 1; if (llama_decode(ctx, llama_batch_get_one(&gen[i], 1))) return 1; }
+            llama_free(ctx);
+            llama_model_free(model);
+        }
+        if (set_fuse) set_fuse(1);
+        double worst[3] = { 0, 0, 0 }, first[3] = { 0, 0, 0 }, fuse_diff = 0, fuse_nmse = 0, fuse_first = 0;       // kqv_out / ffn_out / l_out (+ result_norm): all layers; layer 0 of the prompt
+        size_t n_cmp = 0;
+        for (auto & kv : taps[0].got) {
+            auto it = taps[1].got.find(kv.first);
+            if (it == taps[1].got.end() || it->second.size() != kv.second.size()) { fprintf(stderr, "tensor %s missing in the device run\n", kv.first.c_str()); return 1; }
+            double num = 0, den = 0;
+            for (size_t i = 0; i < kv.second.size(); ++i) { const double d = (double) kv.second[i] - it->second[i]; num += d * d; den += (double) kv.second[i] * kv.second[i]; }
+            const double nmse = den > 0 ? num / den : num;
+            const char * nm = strchr(kv.first.c_str(), ':') + 1;
+            const int cls = !strncmp(nm, "kqv_out", 7) ? 0 : (!strncmp(nm, "ffn_out", 7) || !strncmp(nm, "ffn_moe_out", 11)) ? 1 : 2;
+            worst[cls] = std::max(worst[cls], std::isfinite(nmse) ? nmse : 1e30);
+            if (kv.first.rfind("0:", 0) == 0 && strlen(nm) > 2 && !strcmp(nm + strlen(nm) - 2, "-0")) first[cls] = std::max(first[cls], nmse);
+            auto iu = taps[2].got.find(kv.first);
+            if (iu != taps[2].got.end() && iu->second.size() == it->second.size()) {
+                double rms = 0, mx = 0, sq = 0;
+                for (size_t i = 0; i < it->second.size(); ++i) {
+                    const double d = (double) it->second[i] - iu->second[i];
+                    rms += (double) it->second[i] * it->second[i]; mx = std::max(mx, fabs(d)); sq += d * d;
+                }
+                fuse_nmse = std::max(fuse_nmse, rms > 0 ? sq / rms : sq);
+                rms = sqrt(rms / std::max<size_t>(it->second.size(), 1));
+                fuse_diff = std::max(fuse_diff, rms > 0 ? mx / rms : mx);
+                if (kv.first.rfind("0:", 0) == 0 && strlen(nm) > 2 && !strcmp(nm + strlen(nm) - 2, "-0") && cls == 0) fuse_first = std::max(fuse_first, rms > 0 ? mx / rms : mx);
+                if (mx > 0 || !extra.empty()) fprintf(stderr, "layers: %-28s nmse vs cpu %.3e, fused vs per node max|d|/rms %.3e\n", kv.first.c_str(), nmse, rms > 0 ? mx / rms : mx);
+            }
+            ++n_cmp;
+        }
+        printf("{\"mode\": \"layers\", \"gguf\": \"%s\", \"devices\": \"%s\", \"n_prompt\": %d, \"n_gen\": %d, \"tensors\": %zu, "
+               "\"worst_nmse\": {\"kqv_out\": %.3e, \"ffn_out\": %.3e, \"l_out\": %.3e}, \"layer0_prompt_nmse\": {\"kqv_out\": %.3e, \"ffn_out\": %.3e, \"l_out\": %.3e}, "
+               "\"fused_vs_per_node\": {\"worst_nmse\": %.3e, \"worst_max_over_rms\": %.3e, \"layer0_prompt_kqv_out_max_over_rms\": %.3e}, \"per_node_run\": %s}\n",
+               gguf, devs.c_str(), n_prompt, n_gen, n_cmp, worst[0], worst[1], worst[2], first[0], first[1], first[2], fuse_nmse, fuse_diff, fuse_first, set_fuse ? "true" : "false");
         return 0;
     }
     fprintf(stderr, "unknown mode %s\n", mode.c_str());

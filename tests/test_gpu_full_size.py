@@ -76,9 +76,11 @@ def test_config_shape_against_oracle(qmm, oracle, cfg, t, k, m):
         else:
             # F16_Q8 prefill: the same int8 activations as the CPU, weights and activations rounded to f16 for the MFMA.  rel-L2 is the
             # round-1 bar; the per-element figure is what "1e-3 rel on the f32 accumulator" asks about: 16k samples of an error whose
-            # rms is 3-5e-4 of the output rms peak at ~4 sigma, so the maximum sits at 1.5-2.5e-3
+            # rms is 3-5e-4 of the output rms peak at ~4 sigma, so the maximum sits at 1.5-2.1e-3 over the 21 shapes.
+            # Round 3 measured an int8-exact MFMA mix at 2.7x the cycles per MAC of this one (profiles/r03_nb4.log), so F16_Q8 stays
+            # the prefill mode and the per-element bar is the measured worst + 20%, not a round number above it
             assert l2 <= 1e-3, (cfg, TYPE_NAMES[t], k, m, n, l2)
-            assert mr <= 4e-3, (cfg, TYPE_NAMES[t], k, m, n, mr)
+            assert mr <= 2.5e-3, (cfg, TYPE_NAMES[t], k, m, n, mr)
         assert torch.equal(y, qmm.mul_mat(t, w, k, x))                                       # deterministic
         if n == 1:
             assert torch.equal(qmm.mul_mat(t, w, k, x * 0.5), y * 0.5)                       # exact homogeneity (power of two)
@@ -122,7 +124,7 @@ def test_mul_mat_id_at_mixtral_size(qmm, oracle, k, m, n_tokens):
     if n_tokens * n_used <= 16:
         assert mr <= 2e-5, mr
     else:
-        assert l2 <= 1e-3 and mr <= 4e-3, (l2, mr)
+        assert l2 <= 1e-3 and mr <= 2.5e-3, (l2, mr)
     assert torch.equal(y, qmm.mul_mat_id(t, w, k, b, ids_full[:, :n_used]))
     # the paired launch (ffn_gate_exps + ffn_up_exps share b and ids) at full size equals two single calls
     if k == 4096:

@@ -104,3 +104,31 @@ def test_fusions_fire_in_llamas_own_graph_order(tmp_path, config, what, per_toke
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     n = sum(1 for l in p.stderr.splitlines() if l.startswith(what))
     assert n >= per_token * 6, (what, n, p.stderr[-1500:])
+
+
+def test_every_layers_outputs_against_the_cpu_backend(gguf):
+    """not the logits alone.  `llama-e2e layers` taps kqv_out, ffn_out and l_out of every layer (and result_norm)
+    through the scheduler's eval callback in three runs of the same tokens (40-token prompt, then two single tokens): the CPU backend,
+    the device with its multi-node launches, the device one launch per node.
+      * the two device runs: the attention launch is another algorithm than kq / soft_max / kqv (one pass, p in f16), so layer 0's
+        kqv_out agrees to f16 rounding (2e-3 of the rms; measured 0 .. 4.2e-4) and the tensors behind it to the bar two correct
+        implementations reach (module docstring); a fusion that mis-fires in llama.cpp's own node order is off by O(1);
+      * layer 0 of the prompt sees the same inputs on both backends: its attention output (three MUL_MATs, rope, one attention) is
+        held to a per-op bar, NMSE 2e-5 (measured 1.8e-7 .. 7.5e-7); ffn_out / l_out of layer 0 sit behind wo, the norm and
+        three more MUL_MATs whose int8 activation roundings the last-bit differences of kqv_out already flip: 1e-3 (measured
+        1.4e-4 .. 2.9e-4, profiles/README.md round 3);
+      * deeper layers inherit the flipped roundings of the layers before them (module docstring): the logits' bar."""
+    r = run("layers", "--gguf", gguf, "-p", "40", "-n", "2", "-t", "8")
+    print(r)
+    assert "MI355X0" in r["devices"] and r["per_node_run"] and r["tensors"] >= 3 * (3 * 2 + 1)
+    assert r["fused_vs_per_node"]["layer0_prompt_kqv_out_max_over_rms"] <= FUSED_VS_PER_NODE_ATTN, r
+    assert r["fused_vs_per_node"]["worst_nmse"] < 5e-3, r
+    for k, v in r["layer0_prompt_nmse"].items():
+        assert v <= (LAYER0_ATTN_NMSE if k.startswith("kqv_out") else LAYER0_NMSE), (k, r)
+    for k, v in r["worst_nmse"].items():
+        assert v < 5e-3, (k, r)
+
+
+LAYER0_ATTN_NMSE = 2e-5
+LAYER0_NMSE = 1e-3
+FUSED_VS_PER_NODE_ATTN = 2e-3
