@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -59,6 +60,10 @@ struct mi355x_device_ctx {
     size_t      ring_bytes = 0, ring_pos = 0;
     bool        staged_pending = false;
     std::mutex  ring_mu;
+    // what this module has queued on the device's stream / what a synchronize has waited for: ggml_backend_sched synchronizes a backend
+    // in front of every split input and behind every graph (six calls per generated token, five of them with nothing queued since the
+    // last one); a wait on an idle stream still costs ~9 us of host time (round 3, GGML_MI355X_TIMING), so those return at once
+    std::atomic<uint64_t> enq{0}, enq_synced{0};
 };
 
 // SURVEY 8f-2, weight repack: Q4_0 / Q8_0 / Q6_K weight tensors are re-laid into aligned planes (qmm_repack_rows) the first time
@@ -275,8 +280,8 @@ bool staged_set(mi355x_buffer_ctx * ctx, void * dst, const void * data, size_t s
     memcpy(d->ring + d->ring_pos, data, size);
     if (qmm_memcpy_h2d_async(d->qmm, dst, d->ring + d->ring_pos, size, qmm_stream(d->qmm))) return false;
     d->ring_pos += need;
-    d->staged_pending = true;
-    return true;
+    d->staged_pending = true;       // (not counted in enq: the copy is ordered in front of everything queued later, its source is the ring, and every
+    return true;                    //  other way to the destination settles the stream first: a synchronize need not wait for it)
 }
 
 void buffer_set_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
@@ -1198,6 +1203,7 @@ void backend_set_tensor_async(ggml_backend_t backend, struct ggml_tensor * tenso
     host_timer timer_(3);
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     GGML_ASSERT(on_device(tensor, ctx->dev) && "set_tensor_async: tensor is not in this device's buffer type");
+    ctx->dev->enq++;
     if (mi355x_buffer_ctx * bc = our_buffer_ctx(tensor)) planar_release(bc, (const char *) tensor->data + offset, size, true, qmm_stream(ctx->dev->qmm));
     if (qmm_memcpy_h2d_async(ctx->dev->qmm, (char *) tensor->data + offset, data, size, qmm_stream(ctx->dev->qmm)))
         GGML_ABORT("MI355X set_tensor_async: %s", qmm_last_error());
@@ -1206,6 +1212,7 @@ void backend_get_tensor_async(ggml_backend_t backend, const struct ggml_tensor *
     host_timer timer_(4);
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     GGML_ASSERT(on_device(tensor, ctx->dev) && "get_tensor_async: tensor is not in this device's buffer type");
+    ctx->dev->enq++;
     if (mi355x_buffer_ctx * bc = our_buffer_ctx(tensor)) planar_release(bc, (const char *) tensor->data + offset, size, false, qmm_stream(ctx->dev->qmm));
     if (qmm_memcpy_d2h_async(ctx->dev->qmm, data, (const char *) tensor->data + offset, size, qmm_stream(ctx->dev->qmm)))
         GGML_ABORT("MI355X get_tensor_async: %s", qmm_last_error());
@@ -1221,6 +1228,7 @@ bool backend_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backend
     if (mi355x_buffer_ctx * bc = our_buffer_ctx(dst)) planar_release(bc, (const char *) dst->data, ggml_nbytes(src), true, qmm_stream(dctx->dev->qmm));
     qmm_ctx * dq = dctx->dev->qmm;
     void * dst_stream = qmm_stream(dq);
+    dctx->dev->enq++;
     if (sctx->dev != dctx->dev) {            // the copy runs on the destination's stream, behind what the source has queued
         if (!sctx->ev_copy) sctx->ev_copy = qmm_event_create(sctx->dev->qmm);
         if (!sctx->ev_copy || qmm_event_record(sctx->dev->qmm, sctx->ev_copy, qmm_stream(sctx->dev->qmm)) ||
@@ -1237,6 +1245,7 @@ void backend_event_record(ggml_backend_t backend, ggml_backend_event_t event) {
 }
 void backend_event_wait(ggml_backend_t backend, ggml_backend_event_t event) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
+    ctx->dev->enq++;
     if (qmm_stream_wait_event(ctx->dev->qmm, qmm_stream(ctx->dev->qmm), (qmm_event *) event->context))
         GGML_ABORT("MI355X event_wait: %s", qmm_last_error());
 }
@@ -1244,9 +1253,12 @@ void backend_event_wait(ggml_backend_t backend, ggml_backend_event_t event) {
 void backend_synchronize(ggml_backend_t backend) {
     host_timer timer_(6);
     auto * ctx = (mi355x_backend_ctx *) backend->context;
+    const uint64_t queued = ctx->dev->enq.load();
+    if (queued == ctx->dev->enq_synced.load()) return;       // nothing queued by this module since the last wait on this stream
     if (qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm)))
         GGML_LOG_ERROR("MI355X synchronize: %s\n", qmm_last_error());
     { std::lock_guard<std::mutex> lock(ctx->dev->ring_mu); ctx->dev->staged_pending = false; }
+    ctx->dev->enq_synced.store(queued);
 }
 
 // the analysis step of a graph_compute call
@@ -1745,6 +1757,7 @@ static double wall_us() {
 enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
     const bool timing = GGML_MI355X_TIMING();
+    const uint64_t queued = ++ctx->dev->enq;
     const double t_enter = timing ? wall_us() : 0;
     if (timing) {
         bool one = true;
@@ -1870,6 +1883,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
     }
     free_retired();                 // (the root has waited for every device's slice: nothing queued reads an outgrown staging block)
     { std::lock_guard<std::mutex> lock(ctx->dev->ring_mu); ctx->dev->staged_pending = false; }
+    if (ctx->dev->enq.load() == queued) ctx->dev->enq_synced.store(queued);
     if (timing && ctx->ev_t0 && ctx->ev_t1) {
         float ms = 0.0f;
         int64_t n_tok = 1;                                   // tokens of the ubatch = ne[1] of the widest 2-D activation in the graph

@@ -344,10 +344,23 @@ struct RopeParams {
     float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
 };
 // cos / sin of pair p at position pos (rope_yarn + ggml_rope_cache_init, ggml-cpu.c:8610-8648): theta by the CPU's repeated f32 multiply
+__device__ __forceinline__ void rope_cs_ff(const float pos, const uint32_t p, const RopeParams & rp, const float ffp, float & c, float & s);
 __device__ __forceinline__ void rope_cs(const float pos, const uint32_t p, const RopeParams & rp, const float * __restrict__ ff, float & c, float & s) {
+    rope_cs_ff(pos, p, rp, ff ? ff[p] : 1.0f, c, s);
+}
+// (ffp: the pair's frequency factor, already loaded)
+__device__ __forceinline__ void rope_cs_ff(const float pos, const uint32_t p, const RopeParams & rp, const float ffp, float & c, float & s) {
     float theta = pos;
-    for (uint32_t k = 0; k < p; ++k) theta *= rp.theta_scale;
-    const float theta_extrap = theta / (ff ? ff[p] : 1.0f);
+    if (rp.n_dims <= 128) {
+        // the CPU's repeated multiply, lane p keeping step p of it: 64 straight-line steps.  (As `for (k < p)` the trip count
+        // differs per lane and every step pays a compare, an exec update and a branch: 1.2 us of the decode attention's prologue)
+        float t = pos;
+#pragma unroll
+        for (uint32_t k = 0; k < 64; ++k) { theta = k == p ? t : theta; t *= rp.theta_scale; }
+    } else {
+        for (uint32_t k = 0; k < p; ++k) theta *= rp.theta_scale;
+    }
+    const float theta_extrap = theta / ffp;
     const float theta_interp = rp.freq_scale * theta_extrap;
     float th = theta_interp, mscale = rp.attn_factor;
     if (rp.ext_factor != 0.0f) {
@@ -359,10 +372,16 @@ __device__ __forceinline__ void rope_cs(const float pos, const uint32_t p, const
     // th can be thousands of radians (position times the first frequencies): ocml's sinf / cosf take their large-argument
     // path there.  One reduction in double (exact to ~1e-13 rad) and the fast pair on the remainder give the same values
     // to f32 rounding at a fraction of the instructions.
+    // Round 3: the reduction goes to the quadrant, |y| <= pi/4, and the pair comes from the two short polynomials libm itself uses
+    // on that interval (cephes sinf / cosf, ~1 ulp): a third of the instructions of ocml's pair, which re-check the argument's range.
     const double td = (double) th;
-    const float r = (float) (td - 6.283185307179586 * rint(td * 0.15915494309189535));
-    c = cosf(r) * mscale;
-    s = sinf(r) * mscale;
+    const double qd = rint(td * 0.6366197723675814);
+    const float y = (float) fma(qd, -1.5707963267948966, td), z = y * y;
+    const float ys = y + y * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+    const float yc = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    const int q = (int) (long long) qd & 3;
+    c = (q == 0 ? yc : q == 1 ? -ys : q == 2 ? -yc : ys) * mscale;
+    s = (q == 0 ? ys : q == 1 ? yc : q == 2 ? -ys : -yc) * mscale;
 }
 // one pair of one row; TD = float or __half (the K-cache store of build_attn is rope(k) -> f16)
 template <typename TD>
@@ -758,11 +777,22 @@ struct AttnFresh {
     RopeParams rp;
     int32_t N, j0;
 };
+#ifdef ATTN_STAMPS                      // development builds only (profiles/tools/attn_dev.hip): 100 MHz stamps of workgroup phases
+__device__ unsigned long long attn_stamps[64][8];
+#define ATTN_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 64) attn_stamps[blockIdx.x][slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ATTN_STAMP(slot) do { } while (0)
+#endif
 template <int D, bool FRESH>
 __global__ void __launch_bounds__(1024)
 attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
     extern __shared__ float sc[];                       // n_kv scores, then probabilities [FRESH: + q row f32, new K rows, new V rows f16]
     __shared__ float red[16];
+    ATTN_STAMP(0);
+    // (all kernel arguments in one round trip: see attn_decode_short_kernel)
+    asm volatile("" :: "s"(g.q), "s"(g.k), "s"(g.v), "s"(g.mask), "s"(g.q_nb1), "s"(g.q_nb2), "s"(g.k_nb1), "s"(g.k_nb2), "s"(g.v_nb1), "s"(g.v_nb2), "s"(g.m_nb1),
+                 "s"(g.n_kv), "s"(g.gqa), "s"(g.Dv));
+    if (FRESH) asm volatile("" :: "s"(f.kraw), "s"(f.vraw), "s"(f.pos), "s"(f.ff), "s"(f.kraw_nbh), "s"(f.kraw_nbn), "s"(f.vraw_nbn), "s"(f.N));
     const int h = blockIdx.x, n = blockIdx.y, hk = h / g.gqa;
     const int tid = threadIdx.x, l8 = tid & 7, grp = tid >> 3;          // 128 groups of 8 lanes: one K row per group
     constexpr int CH = D / 8;                           // halves of a K row per lane
@@ -822,7 +852,9 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
             qs[2 * t] = x0 * c - x1 * s;
             qs[2 * t + 1] = x0 * s + x1 * c;
         }
+        ATTN_STAMP(1);
         __syncthreads();
+        ATTN_STAMP(2);
 #pragma unroll
         for (int e = 0; e < CH; ++e) qf[e] = (float) (_Float16) qs[l8 * CH + e];
     } else {
@@ -869,7 +901,9 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
         // per layer for 64 KB of K and V), so the softmax is done by EVERY wave for itself from the scores in LDS: one barrier instead
         // of seven, no block reductions, and the wave's eight V rows are requested together instead of in two trips.  A lane owns the
         // eight columns it multiplies (j = 8 lane ...).  Same max, same exponentials; the sum runs in another order than below.
+        ATTN_STAMP(3);
         __syncthreads();                                // sc[] complete
+        ATTN_STAMP(4);
         const int lane = tid & 63, wave = tid >> 6;
         const int jl = lane * 8;
         const bool live = jl < g.n_kv;                  // (n_kv is a multiple of 8: qmm_attn_decode_supported)
@@ -894,6 +928,7 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
         float pr[8], pfresh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) pr[e] = (float) (_Float16) (sv[e] * inv);
+        ATTN_STAMP(5);
         if (FRESH) {                                    // the batch's own positions: probability set aside, column weight 0 (see below)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -926,6 +961,7 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
                 }
             }
         }
+        ATTN_STAMP(6);
         return;
     }
     mx = block_reduce<true>(mx, red);                   // its barriers also publish sc[]
@@ -984,6 +1020,229 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
             }
         }
     }
+}
+
+// Short caches (n_kv <= 512, D and Dv <= 128: token generation inside llama.cpp's first windows, where the launch is a chain of
+// latencies: 64 KB of K and V per head).  Round 3 stamps of the kernel above at n_kv = 256 (profiles/tools/attn_dev.hip): 2.9 us until
+// the new rows are roped and in LDS, 0.9 us scores, 0.8 us softmax, 2.6 us for the V product (its loads requested behind the second
+// barrier), 7.9 us in the kernel for a 10.5 us slot.  This one
+//   * requests EVERYTHING at entry: the thread's share of the new q / k / v values first, then its four K rows, masks and its
+//     eight V rows (the V loads were 1.5 us of exposed latency behind the softmax), and only then starts to compute;
+//   * spreads the preparation of one token over waves 0-3, one per SIMD (q pairs, K pairs, V values; they were waves 0, 4 and 8:
+//     the same SIMD);
+//   * takes one exponential per column (thread j, through LDS) instead of eight per lane in every wave;
+//   * multiplies f16 x f16 into f32 directly (v_fma_mix: the products of the conversions, exactly as before);
+//   * folds the eight V-row sums of a wave into one register with v_permlane32_swap / v_permlane16_swap before the DPP steps
+//     (20 instructions instead of 8 wave_sums).
+// Same arithmetic as the CPU chain (q, p rounded to f16, f32 accumulation, soft_max_kernel's max / exp / sum); sums in another order.
+template <int D, bool FRESH, bool W256>
+__global__ void __launch_bounds__(1024)
+attn_decode_short_kernel(const AttnArgs g, const AttnFresh f) {
+    extern __shared__ float sc[];       // n_kv scores | n_kv exponentials [FRESH: | q row f16 (D halves, D floats reserved) | new K rows f16 | new V rows f16]
+    ATTN_STAMP(0);
+    // every kernel argument the address arithmetic below needs is requested HERE, in one round trip: left to itself hipcc issues the
+    // s_loads where the values are first used, three dependent waits (1.2 us from entry to the first global load, stamped)
+    asm volatile("" :: "s"(g.q), "s"(g.k), "s"(g.v), "s"(g.mask), "s"(g.q_nb1), "s"(g.q_nb2), "s"(g.k_nb1), "s"(g.k_nb2), "s"(g.v_nb1), "s"(g.v_nb2), "s"(g.m_nb1),
+                 "s"(g.n_kv), "s"(g.gqa), "s"(g.Dv));
+    if (FRESH) asm volatile("" :: "s"(f.kraw), "s"(f.vraw), "s"(f.pos), "s"(f.ff), "s"(f.kraw_nbh), "s"(f.kraw_nbn), "s"(f.vraw_nbn), "s"(f.N));
+    const int h = blockIdx.x, n = blockIdx.y, hk = h / g.gqa;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l8 = tid & 7, grp = tid >> 3;
+    constexpr int CH = D / 8, NV = CH / 8, HP = D / 2;
+    constexpr int NR = W256 ? 2 : 4;                    // K rows per 8-lane group (n_kv <= 256: two)
+    constexpr int CPL = W256 ? 4 : 8;                   // cache columns per lane in the softmax and the V product
+    typedef _Float16 hcol __attribute__((ext_vector_type(CPL)));
+    float *    ex   = sc + g.n_kv;
+    _Float16 * qs   = reinterpret_cast<_Float16 *>(ex + g.n_kv);
+    _Float16 * knew = qs + 2 * D;
+    _Float16 * vnew = knew + (FRESH ? f.N * D : 0);
+    // ---- requests.  FRESH: item `it` of the batch's preparation: q pairs [0, HP), K pairs (HP per token), then V values
+    const int nk = FRESH ? f.N * HP : 0, items = FRESH ? HP + nk + f.N * g.Dv : 0;
+    auto item = [&](int it, const float *& p0, const float *& p1, int & tok) {
+        if (it < HP) {
+            const float * pq = (const float *) (g.q + (int64_t) n * g.q_nb1 + (int64_t) h * g.q_nb2);
+            p0 = pq + 2 * it; p1 = p0 + 1; tok = n;
+        } else if (it < HP + nk) {
+            const int n2 = (it - HP) / HP, p = (it - HP) % HP;
+            const float * kr = (const float *) (f.kraw + (int64_t) hk * f.kraw_nbh + (int64_t) n2 * f.kraw_nbn);
+            p0 = kr + 2 * p; p1 = p0 + 1; tok = n2;
+        } else {
+            const int n2 = (it - HP - nk) / g.Dv, d = (it - HP - nk) % g.Dv;
+            p0 = p1 = (const float *) (f.vraw + (int64_t) (hk * g.Dv + d) * 4 + (int64_t) n2 * f.vraw_nbn); tok = n2;
+        }
+    };
+    float x0 = 0.0f, x1 = 0.0f, xff = 1.0f;
+    int32_t xpos = 0;
+    if (FRESH) {
+        const float * p0, * p1; int tok;
+        const int it0 = tid < items ? tid : 0;
+        item(it0, p0, p1, tok);
+        const float * pf = f.ff ? f.ff + (it0 < HP ? it0 : it0 < HP + nk ? (it0 - HP) % HP : 0) : p0;     // the pair's frequency factor
+        // asm: as C++ loads hipcc sinks these four into the branches that use them, BEHIND the cache loads below (vmcnt retires in
+        // order), and as volatile loads it waits for each.  The wait that releases them counts the cache loads: see below
+        const int32_t * pp = f.pos + tok;
+        asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off"
+                     : "=&v"(xpos), "=&v"(x0), "=&v"(x1), "=&v"(xff) : "v"(pp), "v"(p0), "v"(p1), "v"(pf) : "memory");
+    }
+    h16x8 kv[NR][NV];
+    float mk[NR];
+    {
+        const float * pm = (const float *) (g.mask + (int64_t) n * g.m_nb1);
+        const char *  pk = g.k + (int64_t) hk * g.k_nb2 + (int64_t) l8 * CH * 2;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int j = grp + 128 * r, jc = j < g.n_kv ? j : g.n_kv - 1;
+            const h16x8 * row = (const h16x8 *) (pk + (int64_t) jc * g.k_nb1);
+#pragma unroll
+            for (int c = 0; c < NV; ++c) kv[r][c] = row[c];
+            mk[r] = pm[jc];
+        }
+    }
+    const int jl = lane * CPL;
+    const bool live = jl < g.n_kv;                      // (n_kv is a multiple of 8: qmm_attn_decode_supported)
+    hcol vv[8];
+    {
+        const char * pv = g.v + (int64_t) hk * g.v_nb2 + (int64_t) (live ? jl : 0) * 2;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {                   // rows wave + 16 r
+            const int d = wave + 16 * r < g.Dv ? wave + 16 * r : 0;
+            vv[r] = *(const hcol *) (pv + (int64_t) d * g.v_nb1);
+        }
+    }
+    _Float16 qh[CH];
+    if (!FRESH) {
+        const float * pq = (const float *) (g.q + (int64_t) n * g.q_nb1 + (int64_t) h * g.q_nb2) + l8 * CH;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) qh[e] = (_Float16) pq[e];
+    }
+    ATTN_STAMP(7);
+    // ---- the batch's own rows: rope(q) -> LDS, rope(k) -> LDS and K cache, v -> LDS and V cache
+    if (FRESH) {
+        constexpr int BEHIND = NR * NV + NR + 8;        // K rows, masks and V rows requested behind the four asm loads
+        static_assert(BEHIND == 20 || BEHIND == 16 || BEHIND == 14 || BEHIND == 12, "vmcnt immediates below");
+        if (BEHIND == 20)      asm volatile("s_waitcnt vmcnt(20)" : "+v"(xpos), "+v"(x0), "+v"(x1), "+v"(xff) :: "memory");
+        else if (BEHIND == 16) asm volatile("s_waitcnt vmcnt(16)" : "+v"(xpos), "+v"(x0), "+v"(x1), "+v"(xff) :: "memory");
+        else if (BEHIND == 14) asm volatile("s_waitcnt vmcnt(14)" : "+v"(xpos), "+v"(x0), "+v"(x1), "+v"(xff) :: "memory");
+        else                   asm volatile("s_waitcnt vmcnt(12)" : "+v"(xpos), "+v"(x0), "+v"(x1), "+v"(xff) :: "memory");
+        if (!f.ff) xff = 1.0f;
+        const bool writer = h % g.gqa == 0 && n == 0;
+        auto prepare = [&](int it, float a, float b, float posf, float ffp) {
+            if (it < HP + nk) {
+                const int p = it < HP ? it : (it - HP) % HP;
+                float c, s;
+                rope_cs_ff(posf, (uint32_t) p, f.rp, ffp, c, s);
+                const _Float16 h0 = (_Float16) (a * c - b * s), h1 = (_Float16) (a * s + b * c);
+                if (it < HP) { qs[2 * p] = h0; qs[2 * p + 1] = h1; }        // (q is rounded to f16 by the product with K anyway)
+                else {
+                    const int n2 = (it - HP) / HP;
+                    knew[n2 * D + 2 * p] = h0; knew[n2 * D + 2 * p + 1] = h1;
+                    if (writer) {
+                        _Float16 * kd = reinterpret_cast<_Float16 *>(f.kd + (int64_t) hk * f.kd_nbh + (int64_t) n2 * f.kd_nbn);
+                        kd[2 * p] = h0; kd[2 * p + 1] = h1;
+                    }
+                }
+            } else {
+                const int n2 = (it - HP - nk) / g.Dv, d = (it - HP - nk) % g.Dv;
+                const _Float16 v = (_Float16) a;
+                vnew[n2 * g.Dv + d] = v;
+                if (writer) *reinterpret_cast<_Float16 *>(f.vd + (int64_t) n2 * 2 + (int64_t) (hk * g.Dv + d) * f.vd_nbc) = v;
+            }
+        };
+        if (wave * 64 < items) {                        // wave-uniform: the other waves go straight to the barrier
+            if (tid < items) prepare(tid, x0, x1, (float) xpos, xff);
+            for (int it = tid + 1024; it < items; it += 1024) {     // batches of several tokens
+                const float * p0, * p1; int tok;
+                item(it, p0, p1, tok);
+                prepare(it, *p0, *p1, (float) f.pos[tok], f.ff && it < HP + nk ? f.ff[it < HP ? it : (it - HP) % HP] : 1.0f);
+            }
+        }
+        ATTN_STAMP(1);
+        __syncthreads();
+        ATTN_STAMP(2);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const h16x8 t = *(const h16x8 *) &qs[l8 * CH + c * 8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qh[c * 8 + e] = t[e];
+        }
+    }
+    // ---- scores
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = grp + 128 * r;
+        if (FRESH && (unsigned) (j - f.j0) < (unsigned) f.N) {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) kv[r][c] = *(const h16x8 *) &knew[(j - f.j0) * D + l8 * CH + c * 8];
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float) kv[r][c][e] * (float) qh[c * 8 + e];
+        s = sum8(s);
+        s = s * g.scale + mk[r];
+        if (j < g.n_kv && l8 == 0) sc[j] = s;
+    }
+    ATTN_STAMP(3);
+    __syncthreads();
+    ATTN_STAMP(4);
+    // ---- softmax: every wave takes the maximum for itself, thread j the exponential of column j
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < CPL; e += 4) {
+        const float4 a = live ? *(const float4 *) &sc[jl + e] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        m = fmaxf(m, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+    }
+    m = wave_max(m);
+    if (tid < g.n_kv) ex[tid] = expf(sc[tid] - m);
+    __syncthreads();
+    float e8[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; e += 4) {
+        const float4 a = live ? *(const float4 *) &ex[jl + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        e8[e] = a.x; e8[e + 1] = a.y; e8[e + 2] = a.z; e8[e + 3] = a.w;
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) sum += e8[e];
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    _Float16 pr[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {                     // the batch's own positions: column weight 0, their rows come from LDS below
+        const bool fresh = FRESH && (unsigned) (jl + e - f.j0) < (unsigned) f.N;
+        pr[e] = fresh ? (_Float16) 0.0f : (_Float16) (e8[e] * inv);
+    }
+    ATTN_STAMP(5);
+    // ---- V product: eight rows per wave, their 64 partial sums each folded pairwise into one register
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        acc[r] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) acc[r] += (float) vv[r][e] * (float) pr[e];
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    float t4[4], t2[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                       // lanes 0-31: row r, lanes 32-63: row r + 4
+        const u32x2 w = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[r]), __float_as_uint(acc[r + 4]), false, false);
+        t4[r] = __uint_as_float(w.x) + __uint_as_float(w.y);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                       // 16-lane rows: r, r + 2, r + 4, r + 6
+        const u32x2 w = __builtin_amdgcn_permlane16_swap(__float_as_uint(t4[r]), __float_as_uint(t4[r + 2]), false, false);
+        t2[r] = __uint_as_float(w.x) + __uint_as_float(w.y);
+    }
+    t2[0] += dpp_mov<DPP_ROW_MIRROR>(t2[0]);
+    t2[1] += dpp_mov<DPP_ROW_MIRROR>(t2[1]);
+    float t = sum8(lane & 8 ? t2[1] : t2[0]);           // lanes 16 R + 8 b ...: row 2 R + b
+    const int d = wave + 16 * (2 * (lane >> 4) + ((lane >> 3) & 1));
+    if (l8 == 0 && d < g.Dv) {
+        if (FRESH)
+            for (int i = 0; i < f.N; ++i) t += (float) (_Float16) (ex[f.j0 + i] * inv) * (float) vnew[i * g.Dv + d];
+        ((float *) (g.dst + (int64_t) n * g.d_nb1) + (int64_t) h * g.Dv)[d] = t;
+    }
+    ATTN_STAMP(6);
 }
 
 // Long caches at batch <= 8: one workgroup per (head, token) walks the whole cache (45 us per layer at n_kv = 4160).  From
@@ -1648,6 +1907,11 @@ int qmm_op_add_rms_norm(qmm_ctx * ctx, const qmm_tensor * a, const qmm_tensor * 
     return launch_rms_norm(ctx->s(stream), a, b, w, dst, sum, eps);
 }
 
+static bool attn_short_on() {                            // GGML_MI355X_ATTN_SHORT=0: the general kernel at every n_kv (A/B runs)
+    static const bool on = [] { const char * e = getenv("GGML_MI355X_ATTN_SHORT"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 int qmm_attn_decode_supported(const qmm_tensor * q, const qmm_tensor * k, const qmm_tensor * v, const qmm_tensor * mask, const qmm_tensor * dst) {
     if (!q || !k || !v || !mask || !dst) return 0;
     if (q->type != G_F32 || k->type != G_F16 || v->type != G_F16 || mask->type != G_F32 || dst->type != G_F32) return 0;
@@ -1694,6 +1958,14 @@ int qmm_attn_decode(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, c
         return QMM_OK;
     }
     const AttnFresh none{};
+    if (attn_short_on() && g.n_kv <= 512 && g.D <= 128 && g.Dv <= 128) {
+        const size_t lds2 = (size_t) g.n_kv * 8;
+        const bool w256 = g.n_kv <= 256;
+        if (g.D == 64) hipLaunchKernelGGL((w256 ? attn_decode_short_kernel<64, false, true> : attn_decode_short_kernel<64, false, false>), grid, dim3(1024), lds2, st, g, none);
+        else           hipLaunchKernelGGL((w256 ? attn_decode_short_kernel<128, false, true> : attn_decode_short_kernel<128, false, false>), grid, dim3(1024), lds2, st, g, none);
+        HIP_TRY(hipGetLastError());
+        return QMM_OK;
+    }
     if (g.D == 64) {
         hipLaunchKernelGGL((attn_decode_kernel<64, false>), grid, dim3(1024), lds, st, g, none);
     } else if (g.D == 128) {
@@ -1834,6 +2106,14 @@ int qmm_attn_decode_rope(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor *
     const dim3 grid((unsigned) g.H, (unsigned) f.N);
     const size_t lds = (size_t) g.n_kv * 4 + (size_t) g.D * 4 + (size_t) f.N * (g.D + g.Dv) * 2;
     hipStream_t st = ctx->s(stream);
+    if (attn_short_on() && g.n_kv <= 512 && g.Dv <= 128) {             // (D <= 128: qmm_attn_decode_rope_supported)
+        const size_t lds2 = lds + (size_t) g.n_kv * 4;
+        const bool w256 = g.n_kv <= 256;
+        if (g.D == 64) hipLaunchKernelGGL((w256 ? attn_decode_short_kernel<64, true, true> : attn_decode_short_kernel<64, true, false>), grid, dim3(1024), lds2, st, g, f);
+        else           hipLaunchKernelGGL((w256 ? attn_decode_short_kernel<128, true, true> : attn_decode_short_kernel<128, true, false>), grid, dim3(1024), lds2, st, g, f);
+        HIP_TRY(hipGetLastError());
+        return QMM_OK;
+    }
     if (g.D == 64) {
         auto kern = attn_decode_kernel<64, true>;
         if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));

@@ -305,6 +305,10 @@ int main(int argc, char ** argv) {
                 pps.push_back(n_prompt / (now_s() - t0));
             }
             if (n_gen > 0) {
+                // llama-bench runs pp512 and tg128 as two tests, each from an empty context (examples/llama-bench/llama-bench.cpp:1619-1643:
+                // one test instance per -p value and one per -n value, llama_kv_self_clear in front of every repetition): the generation
+                // leg does not inherit the prompt's 512 cache positions.  (Until round 3 it did here: tg128 was timed at n_kv 640 - 768.)
+                if (n_prompt > 0) llama_kv_self_clear(s.ctx);
                 const double t0 = now_s();
                 if (test_gen(s, n_gen)) return 1;
                 tgs.push_back(n_gen / (now_s() - t0));

@@ -308,3 +308,51 @@ def test_hand_placed_k_step_equals_the_compiler_scheduled_kernel(qmm_by_r64s, k,
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (k, ms, n, float((a - b).abs().max()))
     if any(l.startswith("mfma_r64_q4k_kernel<8>") for l in labels[0]):
         assert any(l.startswith("mfma_r64s_q4k_kernel") for l in labels[1]), labels
+
+
+@pytest.fixture(scope="module")
+def qmm_by_prep():
+    made = _contexts("GGML_MI355X_PREP_REG", (0, 1))
+    yield made
+    for q in made.values():
+        q.close()
+
+
+@pytest.mark.parametrize("t,k,m,n", [(Q4_K, 4096, 4096, 512), (Q6_K, 14336, 4096, 512), (Q5_K, 8192, 1024, 300), (Q4_K, 28672, 2048, 130), (Q4_K, 1024, 512, 64),
+                                     (Q6_K, 3072, 768, 40), (Q4_K, 5120, 1280, 512)],
+                         ids=["wo", "down-q6k-14-tasks", "q5k-ragged", "70b-down-two-per-wave", "one-task", "three-tasks", "five-tasks"])
+def test_register_resident_prep_equals_the_lds_staged_one(qmm_by_prep, t, k, m, n):
+    """prep_act_q8k_kernel (round 3: a wave quantizes 1024 floats, keeps the int8 in registers, one barrier for the row's largest block
+    scale, every lane converts and stores its own 16 values at the register-B positions) against prep_act_kernel: the same operations
+    on the same values, so every MUL_MAT behind either is the same bits; the trace shows which one ran.  Shapes: 4 .. 28 tasks of 1024
+    (one or two per wave), tokens that do not fill a tile, the Q6_K order (PERM 3) beside the Q4_K / Q5_K one (PERM 2)"""
+    import ggml_hexagon_amd.synth as synth
+    dev = torch.device("cuda", 0)
+    w = synth.synth_weights_torch(t, m, k, dev, seed=k + m)
+    x = torch.rand((n, k), device=dev, generator=torch.Generator(device=dev).manual_seed(n + k)) * 2 - 1
+    outs, labels = {}, {}
+    for v, q in qmm_by_prep.items():
+        o = torch.full((n, m), float("nan"), device=dev)
+        labels[v] = q.trace(lambda: q.mul_mat_group([(t, w)], k, x, [o]))
+        q.synchronize()
+        outs[v] = o
+    assert torch.equal(outs[1].view(torch.int32), outs[0].view(torch.int32)), (t, k, m, n, float((outs[1] - outs[0]).abs().max()))
+    assert torch.isfinite(outs[1]).all()
+    assert any(l.startswith("prep_act_kernel") for l in labels[0]) and any(l.startswith("prep_act_q8k_kernel") for l in labels[1]), labels
+
+
+@pytest.mark.parametrize("n_tokens", [64, 512])
+def test_register_resident_prep_in_the_expert_path(qmm_by_prep, n_tokens):
+    """the same comparison through MUL_MAT_ID: the prep gathers the pairs' src1 rows in expert order (live rows from a device word)"""
+    import ggml_hexagon_amd.synth as synth
+    dev = torch.device("cuda", 0)
+    n_expert, n_used, k, m = 8, 2, 4096, 2048
+    w = synth.synth_weights_torch(Q4_K, n_expert * m, k, dev, seed=5).reshape(n_expert, m, -1)
+    g = torch.Generator(device=dev).manual_seed(n_tokens)
+    ids = torch.stack([torch.randperm(n_expert, device=dev, generator=g)[:n_used] for _ in range(n_tokens)]).to(torch.int32)
+    b = torch.rand((n_tokens, 1, k), device=dev, generator=g) * 2 - 1
+    outs = {}
+    for v, q in qmm_by_prep.items():
+        outs[v] = q.mul_mat_id(Q4_K, w, k, b, ids)
+        q.synchronize()
+    assert torch.equal(outs[1].view(torch.int32), outs[0].view(torch.int32))
