@@ -19,14 +19,14 @@ EXPORTS = [
     "qmm_memcpy_d2h", "qmm_memcpy_d2d", "qmm_memset", "qmm_synchronize", "qmm_memcpy2d_d2d", "qmm_event_create",
     "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_event_create_timing", "qmm_event_elapsed_ms", "qmm_memcpy_h2d_async",
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_planar_type", "qmm_repack_rows", "qmm_dequantize",
-    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_swiglu_in", "qmm_mul_mat_id", "qmm_mul_mat_id_pair",
+    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_swiglu_in", "qmm_mul_mat_id", "qmm_mul_mat_id_pair", "qmm_mul_mat_id_swiglu_supported", "qmm_mul_mat_id_swiglu",
     "qmm_chain_begin", "qmm_chain_flush", "qmm_chain_end", "qmm_chain_stats", "qmm_chain_debug", "qmm_trace_begin", "qmm_trace_end",
     "qmm_comm_create", "qmm_comm_destroy", "qmm_comm_size", "qmm_comm_broadcast", "qmm_comm_gather", "qmm_comm_all_gather",
 ]
 # include/ggml_mi355x_ops.h: the glue ops of a transformer layer
 OPS_EXPORTS = [
     "qmm_op_supported", "qmm_op_compute", "qmm_op_add_rms_norm_supported", "qmm_op_add_rms_norm",
-    "qmm_attn_decode_supported", "qmm_attn_decode", "qmm_attn_prefill_supported", "qmm_attn_prefill", "qmm_rope_kv_store_supported", "qmm_rope_kv_store", "qmm_attn_decode_rope_supported", "qmm_attn_decode_rope", "qmm_moe_router_supported", "qmm_moe_router", "qmm_moe_combine_supported", "qmm_moe_combine",
+    "qmm_attn_decode_supported", "qmm_attn_decode", "qmm_attn_prefill_supported", "qmm_attn_prefill", "qmm_rope_kv_store_supported", "qmm_rope_kv_store", "qmm_attn_decode_rope_supported", "qmm_attn_decode_rope", "qmm_moe_router_supported", "qmm_moe_router", "qmm_moe_router_logits_supported", "qmm_moe_router_logits", "qmm_moe_combine_supported", "qmm_moe_combine",
 ]
 
 
@@ -119,10 +119,13 @@ def load_library() -> C.CDLL:
     lib.qmm_attn_prefill.argtypes = [v, P, P, P, P, P, C.c_float, v]
     lib.qmm_moe_combine.argtypes = [v, P, P, P, v]
     lib.qmm_moe_router.argtypes = [v, P, P, P, i64, i32, v]
+    lib.qmm_moe_router_logits.argtypes = [v, P, P, P, P, P, i64, i32, v]
     lib.qmm_rope_kv_store.argtypes = [v, P, P, P, P, P, P, P, P, v]
     lib.qmm_attn_decode_rope.argtypes = [v, P, P, P, P, P, P, P, P, P, P, P, P, C.c_float, i64, v]
     lib.qmm_mul_mat_id.argtypes = [v, i32, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, i64, i64, v]
     lib.qmm_mul_mat_id_pair.argtypes = [v, i32, v, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, v, i64, i64, v]
+    lib.qmm_mul_mat_id_swiglu_supported.argtypes = [i64, i64]
+    lib.qmm_mul_mat_id_swiglu.argtypes = [v, i32, v, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, i64, i64, v]
     for f in (lib.qmm_chain_begin, lib.qmm_chain_flush, lib.qmm_chain_end):
         f.argtypes = [v]
     lib.qmm_chain_stats.argtypes = [v, C.POINTER(i32), C.POINTER(i32)]
@@ -306,6 +309,18 @@ class Qmm:
                                           b.data_ptr(), ne11, b.stride(1) * 4, b.stride(0) * 4,
                                           ids.data_ptr(), n_used, n_tokens, ids.stride(0) * 4,
                                           out.data_ptr(), out.stride(1) * 4, out.stride(0) * 4, self._stream()))
+        return out
+
+    def mul_mat_id_swiglu(self, t, w_gate, w_up, k, b, ids, out):
+        """silu(ffn_gate_exps . b) * (ffn_up_exps . b) for a few (token, slot) pairs in one launch"""
+        n_expert, m = w_gate.shape[0], w_gate.shape[1]
+        n_tokens, ne11 = b.shape[0], b.shape[1]
+        n_used = ids.shape[1]
+        assert ids.stride(1) == 1 and w_up.shape == w_gate.shape and w_up.stride() == w_gate.stride()
+        self._chk(self.lib.qmm_mul_mat_id_swiglu(self.ctx, t, w_gate.data_ptr(), w_up.data_ptr(), w_gate.stride(1), w_gate.stride(0), k, m, n_expert,
+                                                 b.data_ptr(), ne11, b.stride(1) * 4, b.stride(0) * 4,
+                                                 ids.data_ptr(), n_used, n_tokens, ids.stride(0) * 4,
+                                                 out.data_ptr(), out.stride(1) * 4, out.stride(0) * 4, self._stream()))
         return out
 
     def mul_mat_id_pair(self, t, w0, w1, k, b, ids, out0, out1):

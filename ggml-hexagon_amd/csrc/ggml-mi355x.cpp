@@ -1050,6 +1050,47 @@ enum ggml_status compute_mul_mat_id(mi355x_backend_ctx * ctx, ggml_tensor * cons
         const ggml_tensor * dst1 = nodes[twin];
         const int t0 = weight_type(ctx, as), t1 = weight_type(ctx, dst1->src[0]);
         if (t0 != t1) { GGML_LOG_ERROR("MI355X MUL_MAT_ID pair: layouts differ\n"); return GGML_STATUS_FAILED; }
+        // Token generation: the SwiGLU behind the pair (ggml_silu of one, ggml_mul with the other: ffn_moe_gate_par) in the same launch
+        // (round 3).  gate, up and the silu are then never written: each must have exactly the one reader of the pattern, all of them
+        // provably in this split (analyze_readers); the product is written HERE, two or three nodes early, while other workgroups still
+        // stage src1 and read the ids, and across whatever else the graph lists in between.
+        if (qmm_mul_mat_id_swiglu_supported(ids->ne[0], ids->ne[1]) && !getenv("GGML_MI355X_MOE_SWIGLU_OFF")) {
+            auto uses = [&](const ggml_tensor * t) {
+                const auto & rd = ctx->readers;
+                auto it = std::lower_bound(rd.begin(), rd.end(), t, [](const mi355x_backend_ctx::reader_info & x, const ggml_tensor * y) { return x.t < y; });
+                return it != rd.end() && it->t == t ? it->uses : 1 << 20;
+            };
+            int i_silu = 0, i_mul = 0;
+            std::vector<const ggml_tensor *> between;
+            for (int i = 1; i < n_nodes && i <= 2 * LOOKAHEAD && !i_mul; ++i) {
+                const ggml_tensor * t = nodes[i];
+                if (i == twin || done[i] || is_noop(t)) continue;
+                if (!i_silu && t->op == GGML_OP_UNARY && ggml_get_unary_op(t) == GGML_UNARY_OP_SILU && (t->src[0] == dst || t->src[0] == dst1)) { i_silu = i; continue; }
+                if (i_silu && t->op == GGML_OP_MUL) {
+                    const ggml_tensor * sl = nodes[i_silu], * other = sl->src[0] == dst ? dst1 : dst;
+                    if ((t->src[0] == sl && t->src[1] == other) || (t->src[1] == sl && t->src[0] == other)) { i_mul = i; continue; }
+                }
+                between.push_back(t);
+            }
+            if (i_silu && i_mul) {
+                const ggml_tensor * sl = nodes[i_silu], * par = nodes[i_mul];
+                const ggml_tensor * gate = sl->src[0], * up = gate == dst ? dst1 : dst;
+                const bool flags_ok = !((gate->flags | up->flags | sl->flags) & GGML_TENSOR_FLAG_OUTPUT);
+                if (flags_ok && uses(gate) == 1 && uses(up) == 1 && uses(sl) == 1 && is_ours(par) && par->type == GGML_TYPE_F32 && ggml_are_same_shape(par, dst) &&
+                    par->nb[0] == 4 && par->nb[1] == dst->nb[1] && par->nb[2] == dst->nb[2] && can_hoist(par, between) && early_write_ok(par, { b, ids })) {
+                    if (qmm_mul_mat_id_swiglu(q, t0, gate->src[0]->data, up->src[0]->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
+                                              (const float *) b->data, b->ne[1], b->nb[1], b->nb[2],
+                                              (const int32_t *) ids->data, ids->ne[0], ids->ne[1], ids->nb[1],
+                                              (float *) par->data, par->nb[1], par->nb[2], qmm_stream(q))) {
+                        GGML_LOG_ERROR("MI355X MUL_MAT_ID + SwiGLU(%s, %s): %s\n", dst->name, dst1->name, qmm_last_error());
+                        return GGML_STATUS_FAILED;
+                    }
+                    if (dbg()) fprintf(stderr, "fused: expert pair + swiglu (%s)\n", par->name);
+                    done[twin] = 1; done[i_silu] = 1; done[i_mul] = 1;
+                    return GGML_STATUS_SUCCESS;
+                }
+            }
+        }
         if (qmm_mul_mat_id_pair(q, t0, as->data, dst1->src[0]->data, as->nb[1], as->nb[2], as->ne[0], as->ne[1], as->ne[2],
                                 (const float *) b->data, b->ne[1], b->nb[1], b->nb[2],
                                 (const int32_t *) ids->data, ids->ne[0], ids->ne[1], ids->nb[1],
@@ -1292,7 +1333,7 @@ void analyze_readers(mi355x_backend_ctx * ctx, const ggml_cgraph * cgraph) {
         for (int i = 0; i + 1 < cgraph->n_nodes; ++i) {
             const ggml_tensor * n0 = cgraph->nodes[i];
             if (n0->op == GGML_OP_RMS_NORM || (n0->op == GGML_OP_UNARY && ggml_get_unary_op(n0) == GGML_UNARY_OP_SILU) ||
-                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT || n0->op == GGML_OP_ROPE || n0->op == GGML_OP_MUL ||
+                n0->op == GGML_OP_SOFT_MAX || n0->op == GGML_OP_MUL_MAT || n0->op == GGML_OP_MUL_MAT_ID || n0->op == GGML_OP_ROPE || n0->op == GGML_OP_MUL ||
                 n0->op == GGML_OP_GET_ROWS || n0->op == GGML_OP_SUM_ROWS || n0->op == GGML_OP_ADD || n0->op == GGML_OP_CONT || n0->op == GGML_OP_DIV)
                 rd.push_back({ n0, 0, -1, true });
         }
@@ -1586,6 +1627,20 @@ int graph_pass::site_moe_combine(int i, ggml_tensor * node, int gop) {
 // soft_max -> argsort -> get_rows -> sum_rows -> div behind the router logits: one launch
 int graph_pass::site_moe_router(int i, ggml_tensor * node, int gop) {
     (void) gop;
+    // entered one node earlier, at the logits' own MUL_MAT (F32 gate_inp, a few tokens), the launch computes the logits too
+    // (qmm_moe_router_logits, round 3): the logits land in their own buffer at their own place in the graph, so nothing about them
+    // changes for any other reader; the ids and the weights are written one node earlier than before, now also beside the reads of
+    // the MUL_MAT's src1, which joins the operands they must stay clear of
+    ggml_tensor * lgt = nullptr;
+    if (node->op == GGML_OP_MUL_MAT && node->src[0]->type == GGML_TYPE_F32 && node->src[1]->type == GGML_TYPE_F32 && node->type == GGML_TYPE_F32 && node->ne[0] <= 64 &&
+        node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 && !GGML_MI355X_FUSE_OFF() && !getenv("GGML_MI355X_ROUTER_LOGITS_OFF")) {
+        int j = i + 1;
+        while (j < n_nodes && (done[j] || is_noop(cgraph->nodes[j]))) ++j;
+        if (j >= n_nodes || cgraph->nodes[j]->op != GGML_OP_SOFT_MAX || cgraph->nodes[j]->src[0] != node) return 0;
+        lgt = node;
+        i = j;
+        node = cgraph->nodes[j];
+    }
     if (node->op == GGML_OP_SOFT_MAX && !node->src[1] && node->ne[0] <= 64 && node->ne[2] == 1 && node->ne[3] == 1 && !GGML_MI355X_FUSE_OFF()) {
         // the MoE router behind its logits (build_moe_ffn): soft_max -> argsort (top_k view) -> get_rows -> sum_rows -> div
         float scale, max_bias;
@@ -1623,9 +1678,21 @@ int graph_pass::site_moe_router(int i, ggml_tensor * node, int gop) {
                 // with the same rows (a wave reads its row first).  The weights are written now, not at the div's place in the graph:
                 // their block must be free here AND clear of the logits: at the div's place the logits are dead, so a non-inplace
                 // dv may sit on them with rows of 4 * n_used bytes against 4 * n_expert; otherwise into the scratch
-                if (!early_write_ok(as, { node->src[0] }, node->src[0])) return 0;
-                if (!(can_hoist(dv, skipped) && early_write_ok(dv, { node->src[0], as })) && !hoist_elsewhere(ctx, dv)) return 0;
+                if (!early_write_ok(as, { node->src[0], lgt ? lgt->src[1] : nullptr, lgt ? lgt->src[0] : nullptr }, node->src[0])) return 0;
+                if (!(can_hoist(dv, skipped) && early_write_ok(dv, { node->src[0], as, lgt ? lgt->src[1] : nullptr, lgt ? lgt->src[0] : nullptr })) && !hoist_elsewhere(ctx, dv)) return 0;
                 const qmm_tensor lg = to_qt(node->src[0], ctx), ids = to_qt(as, ctx), w = to_qt(dv, ctx);
+                if (lgt) {
+                    const qmm_tensor gi = to_qt(lgt->src[0], ctx), xin = to_qt(lgt->src[1], ctx);
+                    if (!is_ours(lgt->src[0]) || is_split(lgt->src[0]) || !qmm_moe_router_logits_supported(&gi, &xin, &lg, &ids, &w, n_used)) return 0;
+                    if (qmm_moe_router_logits(ctx->dev->qmm, &gi, &xin, &lg, &ids, &w, n_used, 1, qmm_stream(ctx->dev->qmm))) {
+                        GGML_LOG_ERROR("MI355X MoE router with logits(%s): %s\n", node->name, qmm_last_error());
+                        return -1;
+                    }
+                    if (dbg()) fprintf(stderr, "fused: moe router (%s) with its logits (%s)\n", node->name, lgt->name);
+                    done[i] = 1;                                                // the soft_max; the caller marks the MUL_MAT it entered with
+                    for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
+                    return 1;
+                }
                 if (qmm_moe_router_supported(&lg, &ids, &w, n_used)) {
                     if (qmm_moe_router(ctx->dev->qmm, &lg, &ids, &w, n_used, 1, qmm_stream(ctx->dev->qmm))) {
                         GGML_LOG_ERROR("MI355X MoE router(%s): %s\n", node->name, qmm_last_error());

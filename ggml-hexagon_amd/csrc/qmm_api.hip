@@ -860,6 +860,34 @@ int qmm_mul_mat_id_pair(qmm_ctx * c, int type, const void * as0, const void * as
                           ids, n_used, n_tokens, ids_nb1, dst0, d_nb1, d_nb2, as1, dst1);
 }
 
+int qmm_mul_mat_id_swiglu_supported(int64_t n_used, int64_t n_tokens) {
+    return n_used > 0 && n_tokens > 0 && n_used * n_tokens <= MOE_MATVEC_MAX_PAIRS;
+}
+
+int qmm_mul_mat_id_swiglu(qmm_ctx * c, int type, const void * as_gate, const void * as_up, int64_t rb, int64_t expert_bytes,
+                          int64_t K, int64_t M, int64_t n_expert,
+                          const float * b, int64_t ne11, int64_t b_nb1, int64_t b_nb2,
+                          const int32_t * ids, int64_t n_used, int64_t n_tokens, int64_t ids_nb1,
+                          float * dst, int64_t d_nb1, int64_t d_nb2, void * stream) {
+    if (!c) return fail(QMM_EINVAL, "null ctx");
+    if (!as_up || !dst) return fail(QMM_EINVAL, "qmm_mul_mat_id_swiglu: second tensor missing");
+    int rc = check_mm(type, as_gate, rb, K, b, K, "qmm_mul_mat_id_swiglu");
+    if (rc) return rc;
+    if (b_nb1 % 16 || b_nb2 % 16 || ids_nb1 % 4 || d_nb1 % 4 || d_nb2 % 4 || expert_bytes % 2 || (ne11 != 1 && ne11 != n_used))
+        return fail(QMM_EINVAL, "qmm_mul_mat_id_swiglu: strides / ne11");
+    if (!qmm_mul_mat_id_swiglu_supported(n_used, n_tokens)) return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_id_swiglu: more than %d (token, slot) pairs", MOE_MATVEC_MAX_PAIRS);
+    if (M <= 0) return QMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    QMM_CHAIN_FLUSH(c);
+    c->id_calls++;
+    hipStream_t st = c->s(stream);
+#define QMM_MVIDS(TT)                                                                                                                  \
+    return launch_matvec_id_swiglu<TT>(c, st, as_gate, as_up, rb, expert_bytes, (int) K, (int) M, (int) n_expert, b, (int) ne11, b_nb1 / 4, b_nb2 / 4, ids, \
+                                       (int) n_used, (int) n_tokens, ids_nb1 / 4, dst, d_nb1 / 4, d_nb2 / 4)
+    QMM_FOR_TYPE(type, QMM_MVIDS)
+#undef QMM_MVIDS
+}
+
 int qmm_chain_begin(qmm_ctx * c) {
     if (!c) return fail(QMM_EINVAL, "qmm_chain_begin: NULL context");
     if (c->chain_on) return fail(QMM_EINVAL, "qmm_chain_begin: already recording");

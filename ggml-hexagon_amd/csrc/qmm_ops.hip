@@ -17,6 +17,7 @@ namespace {
 enum : int { G_F32 = 0, G_F16 = 1, G_I32 = 26 };
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr int DOT_T = 128;           // threads per dst element of mul_mat_dot_block_kernel / per expert of moe_router_logits_kernel
 typedef float    f32x16v __attribute__((ext_vector_type(16)));
 
 struct Shape {           // extents and byte strides of one operand
@@ -654,12 +655,9 @@ mul_mat_f16_kernel(const MmArgs g) {
 // The router of a mixture-of-experts block after its logits (build_moe_ffn, src/llama-graph.cpp:818-858), one launch instead of
 // five: probs = soft_max(logits); ids = argsort(probs, descending) (top-k = its first n_used entries); weights = probs[ids[:n_used]]
 // normalised by their sum (ggml_get_rows, ggml_sum_rows, ggml_div).  One wave per token, lane e holds expert e (n_expert <= 64).
-__global__ void __launch_bounds__(256)
-moe_router_kernel(const char * __restrict__ logits, char * __restrict__ ids, char * __restrict__ weights, const int64_t l_nb1, const int64_t i_nb1,
-                  const int64_t w_nb1, const int n_expert, const int n_used, const int n_tokens, const int normalise) {
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (t >= n_tokens) return;
-    const float x = lane < n_expert ? ((const float *) (logits + (int64_t) t * l_nb1))[lane] : -INFINITY;
+// (the body: one wave, lane e holds the logit of expert e; shared by moe_router_kernel and moe_router_logits_kernel)
+__device__ __forceinline__ void router_of_logits(const float x, const int lane, const int n_expert, const int n_used, const int normalise,
+                                                 int32_t * __restrict__ ids_row, float * __restrict__ weights_row) {
     const float mx = wave_max(x);
     const float e = lane < n_expert ? expf(x - mx) : 0.0f;
     // soft_max_wave_kernel's arithmetic AND its order of additions: there lane g holds four consecutive values and adds them left to
@@ -674,7 +672,7 @@ moe_router_kernel(const char * __restrict__ logits, char * __restrict__ ids, cha
         const float u = __shfl(p, j, 64);
         rank += u > p || (u == p && j < lane);
     }
-    if (lane < n_expert) ((int32_t *) (ids + (int64_t) t * i_nb1))[rank] = lane;
+    if (lane < n_expert) ids_row[rank] = lane;
     const bool sel = lane < n_expert && rank < n_used;
     // sum_rows_kernel adds the selected weights with the weight of rank r on lane r: the same placement here
     float byrank = 0.0f;
@@ -684,7 +682,48 @@ moe_router_kernel(const char * __restrict__ logits, char * __restrict__ ids, cha
         if (lane == r) byrank = v;
     }
     const float sum = wave_sum(byrank);
-    if (sel) ((float *) (weights + (int64_t) t * w_nb1))[rank] = normalise ? p / sum : p;
+    if (sel) weights_row[rank] = normalise ? p / sum : p;
+}
+__global__ void __launch_bounds__(256)
+moe_router_kernel(const char * __restrict__ logits, char * __restrict__ ids, char * __restrict__ weights, const int64_t l_nb1, const int64_t i_nb1,
+                  const int64_t w_nb1, const int n_expert, const int n_used, const int n_tokens, const int normalise) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= n_tokens) return;
+    const float x = lane < n_expert ? ((const float *) (logits + (int64_t) t * l_nb1))[lane] : -INFINITY;
+    router_of_logits(x, lane, n_expert, n_used, normalise, (int32_t *) (ids + (int64_t) t * i_nb1), (float *) (weights + (int64_t) t * w_nb1));
+}
+
+// The router WITH its logits for a few tokens (round 3: 32 of Mixtral's ~390 launches per generated token): logits = gate_inp x
+// (F32 [K, n_expert], build_moe_ffn's first MUL_MAT) and everything moe_router_kernel does, one workgroup per token.  Eight groups of
+// DOT_T = 128 threads take eight experts side by side, each group exactly as mul_mat_dot_block_kernel takes one dst element (the same
+// shares, the same wave reduction, the same order of the wave sums), so the logits row it writes is the per-node kernel's bit for
+// bit; wave 0 then routes the row from LDS.  (First version: four groups of 256, two rounds for Mixtral's eight experts: the launch
+// then took as long as the two it replaced, gpu_ms_per_token 2.94 -> 2.93.)
+__device__ __forceinline__ float dot_f32_share(const float * __restrict__ pa, const float * __restrict__ pb, const int K, const int t);
+__global__ void __launch_bounds__(1024)
+moe_router_logits_kernel(const char * __restrict__ wgt, const char * __restrict__ x, char * __restrict__ logits, char * __restrict__ ids,
+                         char * __restrict__ weights, const int64_t a_nb1, const int64_t b_nb1, const int64_t l_nb1, const int64_t i_nb1, const int64_t w_nb1,
+                         const int K, const int n_expert, const int n_used, const int normalise) {
+    constexpr int NG = 1024 / DOT_T, WPG = DOT_T / 64;     // groups per workgroup (experts side by side), waves per group
+    __shared__ float red[16];
+    __shared__ float lg[64];
+    const int n = blockIdx.x, tid = threadIdx.x, grp = tid / DOT_T, tg = tid % DOT_T, lane = tid & 63, wg = (tid >> 6) % WPG;
+    const float * pb = (const float *) (x + (int64_t) n * b_nb1);
+    for (int e0 = 0; e0 < n_expert; e0 += NG) {              // uniform trip count: every thread meets every barrier
+        const int e = e0 + grp, ec = e < n_expert ? e : n_expert - 1;
+        float s = dot_f32_share((const float *) (wgt + (int64_t) ec * a_nb1), pb, K, tg);
+        s = wave_sum(s);
+        __syncthreads();
+        if (lane == 0) red[grp * WPG + wg] = s;
+        __syncthreads();
+        float r = red[grp * WPG];
+        for (int i = 1; i < WPG; ++i) r += red[grp * WPG + i];
+        if (e < n_expert && tg == 0) { lg[e] = r; ((float *) (logits + (int64_t) n * l_nb1))[e] = r; }
+    }
+    __syncthreads();
+    if (tid < 64)
+        router_of_logits(lane < n_expert ? lg[lane] : -INFINITY, lane, n_expert, n_used, normalise, (int32_t *) (ids + (int64_t) n * i_nb1),
+                         (float *) (weights + (int64_t) n * w_nb1));
 }
 
 // The other end of a mixture-of-experts block (build_moe_ffn, src/llama-graph.cpp:896-911): experts * weights, then the sum over the
@@ -710,26 +749,31 @@ moe_combine_kernel(const char * __restrict__ x, const char * __restrict__ w, cha
     *(float4 *) (out + (int64_t) n * o_nb1 + (int64_t) c * 4) = acc;
 }
 
-// Few outputs with a long K (the MoE router at batch 1: 8 x 4096): one WORKGROUP per dst element, so K is spread over 256 threads
-// instead of 64 (the wave-per-element kernel walks K = 4096 in 64 dependent trips: 27 us per call, 0.87 ms per Mixtral token).
-__global__ void __launch_bounds__(256)
+// Few outputs with a long K (the MoE router at batch 1: 8 x 4096): one WORKGROUP per dst element, so K is spread over DOT_T = 128
+// threads (256 until round 3: eight experts then did not fit one workgroup of moe_router_logits_kernel side by side) instead of 64 (the wave-per-element kernel walks K = 4096 in 64 dependent trips: 27 us per call, 0.87 ms per Mixtral token).
+// (thread t of DOT_T's share of the dot product; shared with moe_router_logits_kernel so that both give the same bits)
+__device__ __forceinline__ float dot_f32_share(const float * __restrict__ pa, const float * __restrict__ pb, const int K, const int t) {
+    float s = 0.0f;
+    if ((((uintptr_t) pa | (uintptr_t) pb) & 15) == 0) {
+        const int k4 = K / 4;
+        for (int k = t; k < k4; k += DOT_T) {
+            const float4 x = ((const float4 *) pa)[k], y = ((const float4 *) pb)[k];
+            s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        for (int k = k4 * 4 + t; k < K; k += DOT_T) s += pa[k] * pb[k];
+    } else {
+        for (int k = t; k < K; k += DOT_T) s += pa[k] * pb[k];
+    }
+    return s;
+}
+__global__ void __launch_bounds__(DOT_T)
 mul_mat_dot_block_kernel(const MmArgs g) {
     __shared__ float red[4];
     const int i12 = blockIdx.z % g.ne12, i13 = blockIdx.z / g.ne12;
     const int m = blockIdx.x % g.M, n = blockIdx.x / g.M;
     const float * pa = (const float *) (g.a + (int64_t) (i12 / g.r2) * g.a_nb2 + (int64_t) (i13 / g.r3) * g.a_nb3 + (int64_t) m * g.a_nb1);
     const float * pb = (const float *) (g.b + (int64_t) i12 * g.b_nb2 + (int64_t) i13 * g.b_nb3 + (int64_t) n * g.b_nb1);
-    float s = 0.0f;
-    if ((((uintptr_t) pa | (uintptr_t) pb) & 15) == 0) {
-        const int k4 = g.K / 4;
-        for (int k = threadIdx.x; k < k4; k += 256) {
-            const float4 x = ((const float4 *) pa)[k], y = ((const float4 *) pb)[k];
-            s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-        }
-        for (int k = k4 * 4 + threadIdx.x; k < g.K; k += 256) s += pa[k] * pb[k];
-    } else {
-        for (int k = threadIdx.x; k < g.K; k += 256) s += pa[k] * pb[k];
-    }
+    float s = dot_f32_share(pa, pb, g.K, threadIdx.x);
     s = block_reduce<false>(s, red);
     if (threadIdx.x == 0) *(float *) (g.d + (int64_t) i12 * g.d_nb2 + (int64_t) i13 * g.d_nb3 + (int64_t) n * g.d_nb1 + (int64_t) m * 4) = s;
 }
@@ -1694,7 +1738,7 @@ int launch_mul_mat_f(hipStream_t st, const qmm_tensor * a, const qmm_tensor * b,
         else     hipLaunchKernelGGL((mul_mat_f16_kernel<false>), grid, dim3(256), 0, st, g);
     } else {
         const int64_t e = (int64_t) g.M * g.N;
-        if (e <= 2048 && g.K >= 1024) hipLaunchKernelGGL(mul_mat_dot_block_kernel, dim3((unsigned) e, 1, batch), dim3(256), 0, st, g);
+        if (e <= 2048 && g.K >= 1024) hipLaunchKernelGGL(mul_mat_dot_block_kernel, dim3((unsigned) e, 1, batch), dim3(DOT_T), 0, st, g);
         else                          hipLaunchKernelGGL((mul_mat_dot_kernel<float>), dim3((unsigned) ((e + 3) / 4), 1, batch), dim3(256), 0, st, g);
     }
     HIP_TRY(hipGetLastError());
@@ -2144,6 +2188,30 @@ int qmm_moe_router(qmm_ctx * ctx, const qmm_tensor * logits, const qmm_tensor * 
     const int N = (int) logits->ne[1];
     hipLaunchKernelGGL(moe_router_kernel, dim3((N + 3) / 4), dim3(256), 0, ctx->s(stream), (const char *) logits->data, (char *) ids->data,
                        (char *) weights->data, logits->nb[1], ids->nb[1], (int64_t) n_used * 4, (int) logits->ne[0], (int) n_used, N, normalise);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+int qmm_moe_router_logits_supported(const qmm_tensor * gate_inp, const qmm_tensor * x, const qmm_tensor * logits, const qmm_tensor * ids,
+                                    const qmm_tensor * weights, int64_t n_used) {
+    if (!gate_inp || !x || !qmm_moe_router_supported(logits, ids, weights, n_used)) return 0;
+    if (gate_inp->type != G_F32 || x->type != G_F32) return 0;
+    const int64_t K = gate_inp->ne[0], E = gate_inp->ne[1], N = x->ne[1];
+    // (more tokens: the tiled MUL_MAT + moe_router_kernel; K < 1024: qmm_op(MUL_MAT) takes a wave per element there, another order of additions)
+    if (K < 1024 || K >= ((int64_t) 1 << 30) || E != logits->ne[0] || N != logits->ne[1] || N > 8 || x->ne[0] != K) return 0;
+    if (gate_inp->ne[2] != 1 || gate_inp->ne[3] != 1 || x->ne[2] != 1 || x->ne[3] != 1) return 0;
+    return gate_inp->nb[0] == 4 && x->nb[0] == 4 && gate_inp->nb[1] % 4 == 0 && x->nb[1] % 4 == 0;
+}
+
+int qmm_moe_router_logits(qmm_ctx * ctx, const qmm_tensor * gate_inp, const qmm_tensor * x, const qmm_tensor * logits, const qmm_tensor * ids,
+                          const qmm_tensor * weights, int64_t n_used, int normalise, void * stream) {
+    if (!ctx || !qmm_moe_router_logits_supported(gate_inp, x, logits, ids, weights, n_used))
+        return fail(QMM_EUNSUPPORTED, "qmm_moe_router_logits: operands not supported");
+    HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
+    hipLaunchKernelGGL(moe_router_logits_kernel, dim3((unsigned) x->ne[1]), dim3(1024), 0, ctx->s(stream), (const char *) gate_inp->data, (const char *) x->data,
+                       (char *) logits->data, (char *) ids->data, (char *) weights->data, gate_inp->nb[1], x->nb[1], logits->nb[1], ids->nb[1], (int64_t) n_used * 4,
+                       (int) gate_inp->ne[0], (int) logits->ne[0], (int) n_used, normalise);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }

@@ -104,6 +104,13 @@ QMM_API int qmm_moe_router_supported(const qmm_tensor * logits, const qmm_tensor
 QMM_API int qmm_moe_router(qmm_ctx * ctx, const qmm_tensor * logits, const qmm_tensor * ids, const qmm_tensor * weights, int64_t n_used,
                            int normalise, void * stream);
 
+/* The same with the logits themselves, for up to 8 tokens (token generation): logits = gate_inp [K, n_expert] (F32) x [K, n_tokens],
+ * written to `logits` with the bits qmm_op(MUL_MAT) gives, then the router above; one launch for build_moe_ffn's first six nodes. */
+QMM_API int qmm_moe_router_logits_supported(const qmm_tensor * gate_inp, const qmm_tensor * x, const qmm_tensor * logits, const qmm_tensor * ids,
+                                            const qmm_tensor * weights, int64_t n_used);
+QMM_API int qmm_moe_router_logits(qmm_ctx * ctx, const qmm_tensor * gate_inp, const qmm_tensor * x, const qmm_tensor * logits, const qmm_tensor * ids,
+                                  const qmm_tensor * weights, int64_t n_used, int normalise, void * stream);
+
 /* The other end of the block: out [E, n_tokens] = sum over the used experts of x [E, n_used, n_tokens] * w [1, n_used, n_tokens]
  * (ggml_mul by the router weights, then the ggml_add chain over 2-D views, src/llama-graph.cpp:896-911), in the graph's order. */
 QMM_API int qmm_moe_combine_supported(const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * out);

@@ -233,6 +233,16 @@ QMM_API int qmm_mul_mat_id_pair(qmm_ctx * ctx, int type, const void * as0, const
                                 const int32_t * ids, int64_t n_used, int64_t n_tokens, int64_t ids_nb1,
                                 float * dst0, float * dst1, int64_t d_nb1, int64_t d_nb2, void * stream);
 
+/* The same two tensors with the SwiGLU that follows them in build_moe_ffn (src/llama-graph.cpp:870-894: ffn_moe_gate, ffn_moe_up,
+ * ggml_silu, ggml_mul -> ffn_moe_gate_par): dst[:, s, t] = silu(as_gate[ids[s, t]] . b) * (as_up[ids[s, t]] . b), one launch, for up to 16
+ * (token, slot) pairs (token generation; larger batches: qmm_mul_mat_id_pair and the SILU_MUL op).  Same float operations as those. */
+QMM_API int qmm_mul_mat_id_swiglu_supported(int64_t n_used, int64_t n_tokens);
+QMM_API int qmm_mul_mat_id_swiglu(qmm_ctx * ctx, int type, const void * as_gate, const void * as_up, int64_t w_row_bytes, int64_t expert_bytes,
+                                  int64_t K, int64_t M, int64_t n_expert,
+                                  const float * b, int64_t ne11, int64_t b_nb1, int64_t b_nb2,
+                                  const int32_t * ids, int64_t n_used, int64_t n_tokens, int64_t ids_nb1,
+                                  float * dst, int64_t d_nb1, int64_t d_nb2, void * stream);
+
 /* ---- RCCL exchange for a row split driven from ONE process ----------------------------------------------------------
  * Replaces: the reference's only row-split data path, ggml_cuda_op_mul_mat's cudaMemcpyPeerAsync of src1 to every device and of the
  * dst slices back to the main device (ggml/src/ggml-cuda/ggml-cuda.cu:1365-1673; placement of the slices :1603-1625).  Rank r of a

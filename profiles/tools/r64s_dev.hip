@@ -79,7 +79,7 @@ int main(int argc, char ** argv) {
             printf("round %d %-28s %8.2f us   %7.1f TFLOP/s\n", round, which ? (variant == 2 ? "mfma_r64s_q4k_kernel<2>" : variant & 1 ? "mfma_r64s_q4k_kernel<1>" : "mfma_r64s_q4k_kernel<0>") : "mfma_r64_q4k_kernel<8>", us, flop / us * 1e-6);
         }
     {   // in-kernel stamps of the last r64s launch: cycles and 100 MHz ticks over the K loop of wave 0 of every workgroup
-        static unsigned long long h[4][1024];
+        static unsigned long long h[6][1024];
         CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(r64s_stamp), sizeof(h)));
         const int nwg = std::min<int>(1024, grid.x * grid.y * grid.z);
         std::vector<double> cyc, clk;
@@ -88,6 +88,16 @@ int main(int argc, char ** argv) {
         std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
         if (!cyc.empty()) printf("stamps (%zu workgroups): cycles per K-step median %.0f (min %.0f max %.0f) = %.1f per MFMA; shader clock median %.2f GHz (min %.2f max %.2f); loop starts spread over %.2f us\n",
                                  cyc.size(), cyc[cyc.size() / 2], cyc.front(), cyc.back(), cyc[cyc.size() / 2] / 64.0, clk[clk.size() / 2], clk.front(), clk.back(), (last - first) * 0.01);
+        // phases of thread 0 of every workgroup on the 100 MHz clock: entry -> K loop (prologue), the loop, loop end -> last store issued
+        std::vector<double> pro, loop, epi;
+        unsigned long long e0 = ~0ull, e1 = 0;
+        for (int i = 0; i < nwg; ++i) if (h[3][i]) {
+            pro.push_back((h[2][i] - h[4][i]) * 0.01); loop.push_back(h[1][i] * 0.01); epi.push_back((h[5][i] - h[2][i] - h[1][i]) * 0.01);
+            e0 = std::min(e0, h[4][i]); e1 = std::max(e1, h[5][i]);
+        }
+        std::sort(pro.begin(), pro.end()); std::sort(loop.begin(), loop.end()); std::sort(epi.begin(), epi.end());
+        if (!pro.empty()) printf("phases (us, median [min .. max]): prologue %.2f [%.2f .. %.2f] | K loop %.2f [%.2f .. %.2f] | epilogue %.2f [%.2f .. %.2f] | first entry -> last end %.2f\n",
+                                 pro[pro.size() / 2], pro.front(), pro.back(), loop[loop.size() / 2], loop.front(), loop.back(), epi[epi.size() / 2], epi.front(), epi.back(), (e1 - e0) * 0.01);
     }
     return diff == 0 ? 0 : 1;
 }

@@ -102,17 +102,17 @@ static void moe_block(Graph & G, std::mt19937 & rng, int64_t N, int where) {
     ggml_tensor * probs = ggml_soft_max(G.ctx, logits);                             G.fresh(probs);
     ggml_tensor * sel = ggml_top_k(G.ctx, probs, NU);                               // argsort + view
     ggml_tensor * as = sel->src[0];
-    if (where == 2) G.at(as, o_logits); else if (where == 3) G.at(as, o_logits + NE * 4); else G.fresh(as);
+    if (where == 2) G.at(as, o_logits); else if (where == 3) G.at(as, o_logits + NE * 4); else if (where == 6) G.at(as, G.place[0].off); else G.fresh(as);
     ggml_tensor * wts = ggml_get_rows(G.ctx, ggml_reshape_3d(G.ctx, probs, 1, NE, N), sel);   G.fresh(wts);
     ggml_tensor * w2 = ggml_reshape_2d(G.ctx, wts, NU, N);
     ggml_tensor * ws = ggml_sum_rows(G.ctx, w2);                                    G.fresh(ws);
-    ggml_tensor * dv = ggml_div(G.ctx, w2, ws);                                     G.at(dv, where == 1 ? o_logits : o_dv);
+    ggml_tensor * dv = ggml_div(G.ctx, w2, ws);                                     G.at(dv, where == 1 ? o_logits : where == 7 ? G.place[0].off : o_dv);
     ggml_tensor * w3 = ggml_reshape_3d(G.ctx, dv, 1, NU, N);
     ggml_tensor * cur = ggml_reshape_3d(G.ctx, x, E, 1, N);
     ggml_tensor * up = ggml_mul_mat_id(G.ctx, up_e, cur, sel);                      G.fresh(up);
     ggml_tensor * gate = ggml_mul_mat_id(G.ctx, gate_e, cur, sel);                  G.fresh(gate);
     ggml_tensor * sl = ggml_silu(G.ctx, gate);                                      G.fresh(sl);
-    ggml_tensor * par = ggml_mul(G.ctx, up, sl);                                    G.fresh(par);
+    ggml_tensor * par = ggml_mul(G.ctx, up, sl);                                    if (where == 8) G.at(par, G.place[0].off); else G.fresh(par);   // 8: on x ([F, NU, N] f32 = x's bytes)
     ggml_tensor * ex = ggml_mul_mat_id(G.ctx, down_e, par, sel);                    const size_t o_ex = G.fresh(ex);
     ggml_tensor * exw = ggml_mul(G.ctx, ex, w3);                                    G.fresh(exw);
     ggml_tensor * out = nullptr;
@@ -223,8 +223,12 @@ int main() {
         // with their early-written results forced onto operands of the same launch
         const char * moe_what[] = { "MoE block, free placement", "normalised weights (DIV) placed on the router logits", "argsort ids placed exactly on the logits",
                                     "argsort ids placed on the logits, one row further", "last expert ADD placed on the expert outputs",
-                                    "last expert ADD placed on the expert weights" };
-        for (int where = 0; where <= 5; ++where)
+                                    "last expert ADD placed on the expert weights",
+                                    // round 3: for a few tokens the launch also computes the logits, i.e. reads the block's input while it writes
+                                    "argsort ids placed on the router MUL_MAT's src1", "normalised weights (DIV) placed on the router MUL_MAT's src1",
+                                    // ... and the expert pair writes silu(gate) * up itself, while src1 is still being staged
+                                    "silu(gate) * up of the experts placed on their src1" };
+        for (int where = 0; where <= 8; ++where)
             compare(moe_what[where], N, gpu, cpu, [&](Graph & G, std::mt19937 & rng) { moe_block(G, rng, N, where); });
     }
     ggml_backend_free(gpu);

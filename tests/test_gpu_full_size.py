@@ -356,3 +356,30 @@ def test_register_resident_prep_in_the_expert_path(qmm_by_prep, n_tokens):
         outs[v] = q.mul_mat_id(Q4_K, w, k, b, ids)
         q.synchronize()
     assert torch.equal(outs[1].view(torch.int32), outs[0].view(torch.int32))
+
+
+@pytest.mark.parametrize("t,k,m,n_tokens,n_used", [(Q4_K, 4096, 14336, 1, 2), (Q4_K, 4096, 1024, 8, 2), (Q6_K, 2048, 512, 3, 4), (Q8_0, 1024, 768, 2, 2), (Q4_0, 4096, 640, 1, 6)],
+                         ids=["mixtral-gate-up", "eight-tokens", "q6k", "q8_0", "six-experts-used"])
+def test_expert_pair_with_swiglu_equals_pair_then_silu_mul(qmm, t, k, m, n_tokens, n_used):
+    """qmm_mul_mat_id_swiglu (round 3: ffn_gate_exps, ffn_up_exps and the SwiGLU behind them in one launch for a few (token, slot)
+    pairs) against the launches it replaces: the paired MUL_MAT_ID, then silu(gate) * up in f32 with expf as the SILU_MUL kernel has
+    it.  The mat-vec rows are the same bits; the product is compared at 2 ulp (torch's exp is not bit-for-bit the device's expf)"""
+    import ggml_hexagon_amd.synth as synth
+    dev = torch.device("cuda", 0)
+    n_expert = 8
+    wg = synth.synth_weights_torch(t, n_expert * m, k, dev, seed=k).reshape(n_expert, m, -1)
+    wu = synth.synth_weights_torch(t, n_expert * m, k, dev, seed=k + 1).reshape(n_expert, m, -1)
+    g = torch.Generator(device=dev).manual_seed(n_tokens + m)
+    ids = torch.stack([torch.randperm(n_expert, device=dev, generator=g)[:n_used] for _ in range(n_tokens)]).to(torch.int32)
+    b = torch.rand((n_tokens, 1, k), device=dev, generator=g) * 2 - 1
+    og, ou = torch.empty((n_tokens, n_used, m), device=dev), torch.empty((n_tokens, n_used, m), device=dev)
+    qmm.mul_mat_id_pair(t, wg, wu, k, b, ids, og, ou)
+    out = torch.full((n_tokens, n_used, m), float("nan"), device=dev)
+    labels = qmm.trace(lambda: qmm.mul_mat_id_swiglu(t, wg, wu, k, b, ids, out))
+    qmm.synchronize()
+    want = og / (1.0 + torch.exp(-og)) * ou
+    assert torch.isfinite(out).all()
+    err = (out - want).abs() / want.abs().clamp_min(1e-30)
+    assert float(err[want.abs() > 1e-6].max()) < 3e-7, float(err.max())
+    assert any(l.startswith("matvec_id_swiglu_kernel") for l in labels), labels
+    assert torch.equal(out, qmm.mul_mat_id_swiglu(t, wg, wu, k, b, ids, torch.empty_like(out)))

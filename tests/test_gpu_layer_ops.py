@@ -346,6 +346,41 @@ def test_moe_router_one_launch(qmm, n_tok, n_expert, n_used):
     assert np.allclose(w.cpu().numpy(), sel / sel.sum(axis=1, keepdims=True), rtol=2e-6, atol=1e-7)
 
 
+QMM_OP_MUL_MAT_F = 19          # include/ggml_mi355x_ops.h: QMM_OP_ADD = 1 ... QMM_OP_GET_ROWS = 18, QMM_OP_MUL_MAT_F
+
+
+@pytest.mark.parametrize("n_tok,n_expert,n_used,k", [(1, 8, 2, 4096), (3, 8, 2, 4096), (8, 64, 6, 2048), (2, 6, 3, 1030), (1, 16, 4, 5120)])
+def test_moe_router_with_its_logits_one_launch(qmm, n_tok, n_expert, n_used, k):
+    """qmm_moe_router_logits (round 3): logits = gate_inp x, soft_max, argsort, top-k weights in ONE launch for a few tokens, against the
+    two launches it replaces (qmm_op MUL_MAT on F32 + qmm_moe_router): the same bits in all three outputs.  Shapes: experts that do
+    not fill the four groups of 256 threads (6), the 64-expert limit, K that is not a multiple of 4 (scalar tail)"""
+    from ggml_hexagon_amd import capi
+    rng = np.random.default_rng(n_tok * 7 + n_expert + k)
+    gi = dev(rng.normal(0, 0.05, (n_expert, k)).astype(np.float32))
+    x = dev(rng.normal(0, 1, (n_tok, k)).astype(np.float32))
+    M = capi.QmmTensor.make
+    r = lambda t: capi.C.byref(t)
+    outs = []
+    for fused in (False, True):
+        lg = torch.full((n_tok, n_expert), float("nan"), device="cuda")
+        ids = torch.full((n_tok, n_expert), -1, dtype=torch.int32, device="cuda")
+        w = torch.zeros((n_tok, n_used), device="cuda")
+        tg, tx = M(F32, [k, n_expert], data=gi.data_ptr()), M(F32, [k, n_tok], data=x.data_ptr())
+        tl, ti, tw = M(F32, [n_expert, n_tok], data=lg.data_ptr()), M(I32, [n_expert, n_tok], data=ids.data_ptr()), M(F32, [n_used, n_tok], data=w.data_ptr())
+        if fused:
+            assert qmm.lib.qmm_moe_router_logits_supported(r(tg), r(tx), r(tl), r(ti), r(tw), n_used)
+            qmm._chk(qmm.lib.qmm_moe_router_logits(qmm.ctx, r(tg), r(tx), r(tl), r(ti), r(tw), n_used, 1, qmm._stream()))
+        else:
+            qmm._chk(qmm.lib.qmm_op_compute(qmm.ctx, QMM_OP_MUL_MAT_F, r(tg), r(tx), None, r(tl), qmm._stream()))
+            qmm._chk(qmm.lib.qmm_moe_router(qmm.ctx, r(tl), r(ti), r(tw), n_used, 1, qmm._stream()))
+        qmm.synchronize()
+        outs.append((lg, ids, w))
+    assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2].view(torch.int32), outs[1][2].view(torch.int32))
+    want = x.cpu().numpy().astype(np.float64) @ gi.cpu().numpy().astype(np.float64).T
+    assert np.allclose(outs[1][0].cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("n_tok,n_used,e", [(1, 2, 4096), (70, 2, 1024), (5, 6, 512)])
 def test_moe_combine_one_launch(qmm, n_tok, n_used, e):
     """experts * weights and the sum over the used experts (build_moe_ffn's tail) in one launch, in place over slice 0 as ggml-alloc
