@@ -8,7 +8,7 @@ import ctypes as C
 from . import build as _build
 
 Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 2, 8, 12, 13, 14, 15
-Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL = 3, 6, 7, 10, 11, 20
+Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, IQ4_XS = 3, 6, 7, 10, 11, 20, 23
 ACT_REF, ACT_X86 = 0, 1
 PREC_BF16, PREC_F16_Q8 = 0, 1
 MATVEC_MAX_N = 8

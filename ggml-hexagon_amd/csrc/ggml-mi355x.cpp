@@ -110,6 +110,8 @@ struct mi355x_backend_ctx {
     // ... and where the HOST's time goes around one-token graphs (wall clock, us): between two graph_compute calls (libllama: graph
     // build, scheduler, input copies, sampling-free bookkeeping), in the reader analysis, in the issue loop, waiting in synchronize
     double                           us_outside = 0, us_analyze = 0, us_issue = 0, us_wait = 0, t_exit = 0;
+    double                           pp_outside = 0, pp_analyze = 0, pp_issue = 0, pp_wait = 0, t_exit_pp = 0;   // the same for prompt graphs
+    int64_t                          pp_outside_n = 0;
 };
 
 // GGML_MI355X_GLUE=0: offload the quantized MUL_MAT / MUL_MAT_ID only (the round-1 surface); GGML_MI355X_FUSE=0: no fused pairs
@@ -150,7 +152,7 @@ bool type_supported(enum ggml_type t) {
     // the north-star's five formats plus SURVEY 8f-4's (round 2): any stock Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K_* / IQ4_NL GGUF keeps its
     // matmul weights on the device; the kernel library answers the same question through qmm_row_size() != 0
     return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K ||
-           t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_IQ4_NL;
+           t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_IQ4_NL || t == GGML_TYPE_IQ4_XS;
 }
 
 
@@ -236,10 +238,16 @@ void buffer_memset_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * ten
 bool GGML_MI355X_TIMING();
 struct host_timer {
     static constexpr int N = 8;
-    static double us[N], pend_us[N], tg_us[N];           // all calls; calls since the last graph_compute; calls in front of one-token graphs
-    static long long calls[N], pend_calls[N], tg_calls[N];
+    static double us[N], pend_us[N], tg_us[N], pp_us[N]; // all calls; calls since the last graph_compute; calls in front of one-token / prompt graphs
+    static long long calls[N], pend_calls[N], tg_calls[N], pp_calls[N];
+    static int pp_seen;
     static void flush(bool one_token) {
-        for (int i = 0; i < N; ++i) { if (one_token) { tg_us[i] += pend_us[i]; tg_calls[i] += pend_calls[i]; } pend_us[i] = 0; pend_calls[i] = 0; }
+        for (int i = 0; i < N; ++i) {
+            if (one_token) { tg_us[i] += pend_us[i]; tg_calls[i] += pend_calls[i]; }
+            else if (pp_seen >= 2) { pp_us[i] += pend_us[i]; pp_calls[i] += pend_calls[i]; }      // (in front of the first two prompt graphs: the model's upload, first-use initialisations)
+            pend_us[i] = 0; pend_calls[i] = 0;
+        }
+        if (!one_token) ++pp_seen;
     }
     static const char * name(int i) { static const char * n[N] = { "set_tensor", "get_tensor", "cpy_tensor", "set_tensor_async", "get_tensor_async", "cpy_tensor_async", "synchronize", "event" }; return n[i]; }
     int slot; double t0;
@@ -251,8 +259,9 @@ struct host_timer {
         }
     }
 };
-double host_timer::us[host_timer::N] = { 0 }, host_timer::pend_us[host_timer::N] = { 0 }, host_timer::tg_us[host_timer::N] = { 0 };
-long long host_timer::calls[host_timer::N] = { 0 }, host_timer::pend_calls[host_timer::N] = { 0 }, host_timer::tg_calls[host_timer::N] = { 0 };
+int host_timer::pp_seen = 0;
+double host_timer::us[host_timer::N] = { 0 }, host_timer::pend_us[host_timer::N] = { 0 }, host_timer::tg_us[host_timer::N] = { 0 }, host_timer::pp_us[host_timer::N] = { 0 };
+long long host_timer::calls[host_timer::N] = { 0 }, host_timer::pend_calls[host_timer::N] = { 0 }, host_timer::tg_calls[host_timer::N] = { 0 }, host_timer::pp_calls[host_timer::N] = { 0 };
 
 constexpr size_t STAGED_SET_MAX = (size_t) 256 << 10, STAGED_RING = (size_t) 4 << 20;
 bool staged_set_on() { static const bool on = [] { const char * e = getenv("GGML_MI355X_STAGED_SET"); return !(e && atoi(e) == 0); }(); return on; }
@@ -1222,6 +1231,14 @@ void backend_free(ggml_backend_t backend) {
         if (ctx->graphs_tg > 1)
             fprintf(stderr, "MI355X timing %s: host us per tg graph: outside graph_compute %.1f | reader analysis %.1f | issue loop %.1f | waiting in synchronize %.1f\n", ctx->name.c_str(),
                     ctx->us_outside / (double) (ctx->graphs_tg - 1), ctx->us_analyze / (double) ctx->graphs_tg, ctx->us_issue / (double) ctx->graphs_tg, ctx->us_wait / (double) ctx->graphs_tg);
+        for (int i = 0; i < host_timer::N && ctx->graphs_pp > 0; ++i)
+            if (host_timer::pp_calls[i]) fprintf(stderr, "MI355X timing %s: %s in front of a prompt graph: %.2f calls, %.1f us each, %.1f us per graph\n", ctx->name.c_str(), host_timer::name(i),
+                                                 host_timer::pp_calls[i] / (double) std::max<int64_t>(ctx->graphs_pp - 2, 1), host_timer::pp_us[i] / (double) host_timer::pp_calls[i],
+                                                 host_timer::pp_us[i] / (double) std::max<int64_t>(ctx->graphs_pp - 2, 1));
+        if (ctx->graphs_pp > 1)
+            fprintf(stderr, "MI355X timing %s: host us per pp graph: outside graph_compute %.1f (between consecutive prompt graphs) | reader analysis %.1f | issue loop %.1f | waiting in synchronize %.1f\n",
+                    ctx->name.c_str(), ctx->pp_outside / (double) std::max<int64_t>(ctx->pp_outside_n, 1), ctx->pp_analyze / (double) (ctx->graphs_pp - 1), ctx->pp_issue / (double) (ctx->graphs_pp - 1),
+                    ctx->pp_wait / (double) (ctx->graphs_pp - 1));
         qmm_event_destroy(ctx->dev->qmm, ctx->ev_t0);
         qmm_event_destroy(ctx->dev->qmm, ctx->ev_t1);
     }
@@ -1963,7 +1980,16 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
                 if (ctx->t_exit > 0) ctx->us_outside += t_enter - ctx->t_exit;
                 ctx->us_analyze += t_analyzed - t_enter;  ctx->us_issue += t_issued - t_analyzed;  ctx->us_wait += t_done - t_issued;
                 ctx->t_exit = t_done;
-            } else { ctx->t_exit = 0; ctx->ms_pp += ms; ctx->graphs_pp++; ctx->tokens_pp += n_tok; if (ctx->ms_pp_min == 0 || ms < ctx->ms_pp_min) ctx->ms_pp_min = ms; }
+                ctx->t_exit_pp = 0;
+            } else {
+                ctx->t_exit = 0; ctx->ms_pp += ms; ctx->graphs_pp++; ctx->tokens_pp += n_tok; if (ctx->ms_pp_min == 0 || ms < ctx->ms_pp_min) ctx->ms_pp_min = ms;
+                const double t_done = wall_us();
+                if (ctx->graphs_pp > 1) {                                // (the first prompt graph also re-lays weights at their first use: not a sample)
+                    if (ctx->t_exit_pp > 0 && ctx->graphs_pp > 2) { ctx->pp_outside += t_enter - ctx->t_exit_pp; ctx->pp_outside_n++; }
+                    ctx->pp_analyze += t_analyzed - t_enter;  ctx->pp_issue += t_issued - t_analyzed;  ctx->pp_wait += t_done - t_issued;
+                }
+                ctx->t_exit_pp = t_done;
+            }
         }
     }
     return GGML_STATUS_SUCCESS;

@@ -11,11 +11,11 @@ from __future__ import annotations
 import numpy as np
 
 Q4_0, Q8_0, Q4_K, Q5_K, Q6_K = 2, 8, 12, 13, 14
-Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL = 3, 6, 7, 10, 11, 20      # ggml-common.h:174-207, 253-277, 405-410
-BLCK = {Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q2_K: 256, Q3_K: 256, IQ4_NL: 32}
-TYPE_SIZE = {Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q2_K: 84, Q3_K: 110, IQ4_NL: 18}
+Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, IQ4_XS = 3, 6, 7, 10, 11, 20, 23      # ggml-common.h:174-207, 253-277, 405-418
+BLCK = {Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q2_K: 256, Q3_K: 256, IQ4_NL: 32, IQ4_XS: 256}
+TYPE_SIZE = {Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q2_K: 84, Q3_K: 110, IQ4_NL: 18, IQ4_XS: 136}
 NAMES = {Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K",
-         Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q2_K: "q2_K", Q3_K: "q3_K", IQ4_NL: "iq4_nl"}
+         Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q2_K: "q2_K", Q3_K: "q3_K", IQ4_NL: "iq4_nl", IQ4_XS: "iq4_xs"}
 BY_NAME = {v: k for k, v in NAMES.items()}
 
 
@@ -53,6 +53,8 @@ def synth_weights(t: int, rows: int, k: int, seed: int = 0, sigma: float = 0.02)
         blk[:, 0:2] = _f16_bytes(rng, nb, 3 * sigma / 16)
     elif t == IQ4_NL:
         blk[:, 0:2] = _f16_bytes(rng, nb, 3 * sigma / 127)
+    elif t == IQ4_XS:                                         # w = d*(ls-32)*kvalues[q], |ls-32| <= 32, |kvalues| <= 127
+        blk[:, 0:2] = _f16_bytes(rng, nb, 3 * sigma / 127 / 16)
     elif t == Q2_K:                                           # w = d*(sc&15)*q - dmin*(sc>>4), q <= 3
         blk[:, 80:82] = _f16_bytes(rng, nb, 6 * sigma / 3 / 10, signed=False)
         blk[:, 82:84] = _f16_bytes(rng, nb, 3 * sigma / 10, signed=False)
@@ -98,6 +100,8 @@ def synth_weights_torch(t: int, rows: int, k: int, device, seed: int = 0, sigma:
         blk[:, 0:2] = f16(3 * sigma / 16)
     elif t == IQ4_NL:
         blk[:, 0:2] = f16(3 * sigma / 127)
+    elif t == IQ4_XS:
+        blk[:, 0:2] = f16(3 * sigma / 127 / 16)
     elif t == Q2_K:
         blk[:, 80:82] = f16(6 * sigma / 3 / 10, signed=False)
         blk[:, 82:84] = f16(3 * sigma / 10, signed=False)

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 
-from .synth import Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, row_size
+from .synth import IQ4_XS, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, row_size
 
 
 @dataclass
@@ -85,6 +85,12 @@ def _llama(name, n_layer, n_embd, n_ff, n_head, n_head_kv, n_vocab, recipe, n_ex
             tq = tk = tv = to = tg = td = Q4_0
         elif recipe == "q4_k":                       # north-star synthetic: every matmul weight Q4_K
             tq = tk = tv = to = tg = td = Q4_K
+        elif recipe == "iq4_xs":                     # round 3: llama-quant.cpp:232-234 (attn_v at n_gqa >= 4), :299-301 (ffn_down of the first eighth)
+            tq = tk = tv = to = tg = td = IQ4_XS
+            if n_head // n_head_kv >= 4:
+                tv = Q5_K
+            if i < n_layer // 8:
+                td = Q5_K
         else:                                        # q4_k_m
             tq = tk = to = tg = Q4_K
             tv = td = Q6_K if more else Q4_K
@@ -116,6 +122,8 @@ WORKLOADS = {
     "llama3-70b-q4_k_m":  lambda: _llama("llama3-70b-q4_k_m", 80, 8192, 28672, 64, 8, 128256, "q4_k_m"),
     "mixtral-8x7b-q4_k_m": lambda: _llama("mixtral-8x7b-q4_k_m", 32, 4096, 14336, 32, 8, 32000, "q4_k_m", 8, 2),
     "synth-7b-q4_k":      lambda: _llama("synth-7b-q4_k", 32, 4096, 11008, 32, 32, 32000, "q4_k"),
+    # not a BASELINE config: SURVEY 8f-4's last weight format on the llama3-8b shapes (`bench.py --workload llama3-8b-iq4_xs`)
+    "llama3-8b-iq4_xs":   lambda: _llama("llama3-8b-iq4_xs", 32, 4096, 14336, 32, 8, 128256, "iq4_xs"),
 }
 
 

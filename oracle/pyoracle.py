@@ -20,10 +20,10 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 
 Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 2, 8, 12, 13, 14, 15
-Q4_1, Q5_0, Q5_1, Q8_1, Q2_K, Q3_K, IQ4_NL = 3, 6, 7, 9, 10, 11, 20
+Q4_1, Q5_0, Q5_1, Q8_1, Q2_K, Q3_K, IQ4_NL, IQ4_XS = 3, 6, 7, 9, 10, 11, 20, 23
 TYPE_NAMES = {Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K",
-              Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_1: "q8_1", Q2_K: "q2_K", Q3_K: "q3_K", IQ4_NL: "iq4_nl"}
-WEIGHT_TYPES = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL)
+              Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_1: "q8_1", Q2_K: "q2_K", Q3_K: "q3_K", IQ4_NL: "iq4_nl", IQ4_XS: "iq4_xs"}
+WEIGHT_TYPES = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, IQ4_XS)
 
 
 def vec_dot_type(t: int) -> int:

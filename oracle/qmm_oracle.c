@@ -20,7 +20,7 @@
 int qmo_blck_size(int type) {
     switch (type) {
         case QMO_Q4_0: case QMO_Q8_0: case QMO_Q4_1: case QMO_Q5_0: case QMO_Q5_1: case QMO_Q8_1: case QMO_IQ4_NL: return 32;
-        case QMO_Q2_K: case QMO_Q3_K: case QMO_Q4_K: case QMO_Q5_K: case QMO_Q6_K: case QMO_Q8_K: return 256;
+        case QMO_Q2_K: case QMO_Q3_K: case QMO_Q4_K: case QMO_Q5_K: case QMO_Q6_K: case QMO_Q8_K: case QMO_IQ4_XS: return 256;
         default: return 0;
     }
 }
@@ -34,6 +34,7 @@ size_t qmo_type_size(int type) {
         case QMO_Q5_1: return 24;   /* f16 d, f16 m, 4 high-bit bytes, 16 nibbles   ggml-common.h:195-207 */
         case QMO_Q8_1: return 36;   /* f16 d, f16 s = d * sum(qs), 32 int8          ggml-common.h:216-227 */
         case QMO_IQ4_NL: return 18; /* f16 d, 16 bytes of indices into kvalues_iq4nl ggml-common.h:405-410 */
+        case QMO_IQ4_XS: return 136; /* f16 d, u16 scales_h, 4 scales_l bytes, 128 bytes of table indices  ggml-common.h:411-418 */
         case QMO_Q2_K: return 84;   /* 16 scale|min nibbles, 64 2-bit bytes, f16 d, f16 dmin  ggml-common.h:253-265 */
         case QMO_Q3_K: return 110;  /* 32 hmask, 64 2-bit bytes, 12 scale bytes, f16 d        ggml-common.h:271-277 */
         case QMO_Q4_K: return 144;  /* f16 d, f16 dmin, 12 scale bytes, 128 nibbles ggml-common.h:285-296 */
@@ -53,7 +54,7 @@ int qmo_vec_dot_type(int type) {   /* type_traits_cpu[].vec_dot_type, ggml-cpu.c
     switch (type) {
         case QMO_Q4_0: case QMO_Q8_0: case QMO_Q5_0: case QMO_IQ4_NL: return QMO_Q8_0;
         case QMO_Q4_1: case QMO_Q5_1: return QMO_Q8_1;
-        case QMO_Q2_K: case QMO_Q3_K: case QMO_Q4_K: case QMO_Q5_K: case QMO_Q6_K: return QMO_Q8_K;
+        case QMO_Q2_K: case QMO_Q3_K: case QMO_Q4_K: case QMO_Q5_K: case QMO_Q6_K: case QMO_IQ4_XS: return QMO_Q8_K;
         default: return -1;
     }
 }
@@ -174,6 +175,19 @@ int qmo_dequantize_row(int type, const void *src, float *dst, int64_t k) {
             for (int j = 0; j < 16; ++j) {
                 dst[j]      = d * (float)iq4nl_values[qs[j] & 15];
                 dst[j + 16] = d * (float)iq4nl_values[qs[j] >> 4];
+            }
+        } break;
+        case QMO_IQ4_XS: {                                /* ggml-quants.c:2454-2475: eight sub-blocks of 32, y = d*(ls-32)*kvalues_iq4nl[q] */
+            const float d = rd_f16(blk);
+            const unsigned sh = (unsigned)blk[2] | ((unsigned)blk[3] << 8);
+            const uint8_t *sl = blk + 4, *qs = blk + 8;
+            for (int ib = 0; ib < 8; ++ib, qs += 16) {
+                const int ls = (int)((sl[ib / 2] >> (4 * (ib % 2))) & 0xf) | (int)(((sh >> (2 * ib)) & 3) << 4);
+                const float dl = d * (float)(ls - 32);
+                for (int j = 0; j < 16; ++j) {
+                    dst[32 * ib + j]      = dl * (float)iq4nl_values[qs[j] & 15];
+                    dst[32 * ib + j + 16] = dl * (float)iq4nl_values[qs[j] >> 4];
+                }
             }
         } break;
         case QMO_Q2_K: {                                  /* ggml-quants.c:712-745: 16 sub-blocks of 16, y = d*(sc&15)*q - dmin*(sc>>4) */
@@ -510,6 +524,32 @@ static float dot_q3_K(int64_t k, const uint8_t *w, const uint8_t *a) {   /* ggml
     return acc;
 }
 
+static float dot_iq4_xs(int64_t k, const uint8_t *w, const uint8_t *a) {   /* ggml-cpu-quants.c:12665-13065, the scalar branch (:13037-13063) */
+    float sumf = 0.0f;
+    for (int64_t b = 0; b < k / 256; ++b, w += 136, a += 292) {
+        float yd; memcpy(&yd, a, 4);
+        const float d4d8 = rd_f16(w) * yd;
+        unsigned h = (unsigned)w[2] | ((unsigned)w[3] << 8);
+        const uint8_t *sl = w + 4, *qs = w + 8;
+        const int8_t *q8 = (const int8_t *)(a + 4);
+        for (int ib = 0; ib < 8; ib += 2) {
+            const int ls1 = (int)(sl[ib / 2] & 0xf) | (int)((h << 4) & 0x30);
+            const int ls2 = (int)(sl[ib / 2] >> 4) | (int)((h << 2) & 0x30);
+            h >>= 4;
+            const float d1 = d4d8 * (float)(ls1 - 32), d2 = d4d8 * (float)(ls2 - 32);
+            int sumi1 = 0, sumi2 = 0;
+            for (int j = 0; j < 16; ++j) { sumi1 += q8[j] * iq4nl_values[qs[j] & 0xf]; sumi2 += q8[j + 16] * iq4nl_values[qs[j] >> 4]; }
+            sumf += d1 * (float)(sumi1 + sumi2);
+            qs += 16; q8 += 32;
+            sumi1 = sumi2 = 0;
+            for (int j = 0; j < 16; ++j) { sumi1 += q8[j] * iq4nl_values[qs[j] & 0xf]; sumi2 += q8[j + 16] * iq4nl_values[qs[j] >> 4]; }
+            sumf += d2 * (float)(sumi1 + sumi2);
+            qs += 16; q8 += 32;
+        }
+    }
+    return sumf;
+}
+
 float qmo_vec_dot(int type, int64_t k, const void *w_row, const void *act_row) {
     const uint8_t *w = (const uint8_t *)w_row, *a = (const uint8_t *)act_row;
     switch (type) {
@@ -520,6 +560,7 @@ float qmo_vec_dot(int type, int64_t k, const void *w_row, const void *act_row) {
         case QMO_Q4_1: case QMO_Q5_0: case QMO_Q5_1: case QMO_IQ4_NL: return dot_legacy(type, k, w, a);
         case QMO_Q2_K: return dot_q2_K(k, w, a);
         case QMO_Q3_K: return dot_q3_K(k, w, a);
+        case QMO_IQ4_XS: return dot_iq4_xs(k, w, a);
         default: return NAN;
     }
 }

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 enum { QMO_Q4_0 = 2, QMO_Q4_1 = 3, QMO_Q5_0 = 6, QMO_Q5_1 = 7, QMO_Q8_0 = 8, QMO_Q8_1 = 9, QMO_Q2_K = 10, QMO_Q3_K = 11,
-       QMO_Q4_K = 12, QMO_Q5_K = 13, QMO_Q6_K = 14, QMO_Q8_K = 15, QMO_IQ4_NL = 20 };
+       QMO_Q4_K = 12, QMO_Q5_K = 13, QMO_Q6_K = 14, QMO_Q8_K = 15, QMO_IQ4_NL = 20, QMO_IQ4_XS = 23 };
 
 /* activation rounding variant (all three exist in the reference; bytes differ only on rare ties) */
 enum { QMO_ACT_REF = 0,   /* quantize_row_q8_0_ref: id = 1/(amax/127), roundf          ggml-quants.c:194-217      */

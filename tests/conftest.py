@@ -29,7 +29,7 @@ def ref():
 
 
 GOLDEN = ROOT / "tests" / "golden"
-TYPES = ["q4_0", "q8_0", "q4_K", "q5_K", "q6_K", "q4_1", "q5_0", "q5_1", "q2_K", "q3_K", "iq4_nl"]
+TYPES = ["q4_0", "q8_0", "q4_K", "q5_K", "q6_K", "q4_1", "q5_0", "q5_1", "q2_K", "q3_K", "iq4_nl", "iq4_xs"]
 
 
 @pytest.fixture(scope="session", params=TYPES)

@@ -21,7 +21,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
-from oracle.pyoracle import Q2_K, Q3_K, Q4_0, Q4_1, Q4_K, Q5_0, Q5_1, Q5_K, Q6_K, Q8_0, IQ4_NL, TYPE_NAMES, WEIGHT_TYPES, RefGgml  # noqa: E402
+from oracle.pyoracle import Q2_K, Q3_K, Q4_0, Q4_1, Q4_K, Q5_0, Q5_1, Q5_K, Q6_K, Q8_0, IQ4_NL, IQ4_XS, TYPE_NAMES, WEIGHT_TYPES, RefGgml  # noqa: E402
 import ggml_hexagon_amd.synth as synth  # noqa: E402
 
 K, M = 512, 40

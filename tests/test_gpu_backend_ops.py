@@ -62,15 +62,15 @@ def test_supported_surface_is_the_five_quant_types():
     assert ok >= 45 and unsup == 0, (ok, unsup, out[-1500:])
 
 
-def test_supported_surface_includes_the_next_six_formats():
-    """Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL through the reference's own harness (n = 1..9 covers the mat-vec kernels
+def test_supported_surface_includes_the_next_seven_formats():
+    """Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL and (round 3) IQ4_XS through the reference's own harness (n = 1..9 covers the mat-vec kernels
     and the first MFMA batch size), MUL_MAT and MUL_MAT_ID"""
     rc, out = run_tbo("test", "-o", "MUL_MAT", "-p",
-                      r"type_a=(q4_1|q5_0|q5_1|q2_K|q3_K|iq4_nl),type_b=f32,m=16,n=[1-9],k=256,bs=\[1,1\],nr=\[1,1\],per=\[0,1,2,3\]")
+                      r"type_a=(q4_1|q5_0|q5_1|q2_K|q3_K|iq4_nl|iq4_xs),type_b=f32,m=16,n=[1-9],k=256,bs=\[1,1\],nr=\[1,1\],per=\[0,1,2,3\]")
     ok, fail, unsup = summarize(out)
     assert not fail and rc == 0, "\n".join(fail[:20])
-    assert ok >= 54 and unsup == 0, (ok, unsup, out[-1500:])
-    rc, out = run_tbo("test", "-o", "MUL_MAT_ID", "-p", r"type_a=(q4_1|q5_0|q5_1|q2_K|q3_K|iq4_nl)")
+    assert ok >= 63 and unsup == 0, (ok, unsup, out[-1500:])
+    rc, out = run_tbo("test", "-o", "MUL_MAT_ID", "-p", r"type_a=(q4_1|q5_0|q5_1|q2_K|q3_K|iq4_nl|iq4_xs)")
     ok, fail, unsup = summarize(out)
     assert not fail and rc == 0, "\n".join(fail[:20])
-    assert ok >= 12 and unsup == 0, (ok, unsup, out[-1500:])
+    assert ok >= 14 and unsup == 0, (ok, unsup, out[-1500:])

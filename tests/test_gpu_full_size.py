@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-from oracle.pyoracle import ACT_REF, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, TYPE_NAMES  # noqa: E402
+from oracle.pyoracle import ACT_REF, IQ4_XS, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, TYPE_NAMES  # noqa: E402
 
 # (config, type, K, M): the distinct quantized MUL_MAT shapes of BASELINE.json's configs
 SHAPES = [
@@ -27,6 +27,8 @@ SHAPES = [
     ("llama3-70b-q4_k_m", Q4_K, 8192, 28672), ("llama3-70b-q4_k_m", Q4_K, 28672, 8192), ("llama3-70b-q4_k_m", Q6_K, 28672, 8192),
     ("llama3-70b-q4_k_m", Q6_K, 8192, 128256),
     ("mixtral-8x7b-q4_k_m", Q8_0, 4096, 1024), ("mixtral-8x7b-q4_k_m", Q5_K, 4096, 4096), ("mixtral-8x7b-q4_k_m", Q6_K, 4096, 32000),
+    # not a BASELINE config: SURVEY 8f-4's last format (round 3) on the llama3-8b shapes
+    ("llama3-8b-iq4_xs", IQ4_XS, 4096, 4096), ("llama3-8b-iq4_xs", IQ4_XS, 4096, 14336), ("llama3-8b-iq4_xs", IQ4_XS, 14336, 4096),
 ]
 IDS = [f"{c}:{TYPE_NAMES[t]}-{k}x{m}" for c, t, k, m in SHAPES]
 

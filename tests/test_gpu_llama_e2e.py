@@ -31,7 +31,7 @@ def run(*args, env=None, timeout=600):
     return json.loads(lines[-1]) if lines else None
 
 
-@pytest.fixture(scope="module", params=["tiny-q4_k_m", "tiny-q4_0", "tiny-q5_0", "tiny-q3_k_m", "tiny-mix", "tiny-moe-q4_k_m"])
+@pytest.fixture(scope="module", params=["tiny-q4_k_m", "tiny-q4_0", "tiny-q5_0", "tiny-q3_k_m", "tiny-mix", "tiny-iq4_xs", "tiny-moe-q4_k_m"])
 def gguf(request, tmp_path_factory):
     path = tmp_path_factory.mktemp("gguf") / f"{request.param}.gguf"
     run("write", "--config", request.param, "--gguf", str(path))

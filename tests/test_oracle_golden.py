@@ -14,8 +14,8 @@ def rel_rms(a, b):
 
 def test_type_table(oracle):
     # ggml-common.h block sizes; bytes/weight of SURVEY.md §8d
-    assert [oracle.lib.qmo_type_size(t) for t in ALL] == [18, 34, 144, 176, 210, 20, 22, 24, 84, 110, 18]
-    assert [oracle.lib.qmo_blck_size(t) for t in ALL] == [32, 32, 256, 256, 256, 32, 32, 32, 256, 256, 32]
+    assert [oracle.lib.qmo_type_size(t) for t in ALL] == [18, 34, 144, 176, 210, 20, 22, 24, 84, 110, 18, 136]
+    assert [oracle.lib.qmo_blck_size(t) for t in ALL] == [32, 32, 256, 256, 256, 32, 32, 32, 256, 256, 32, 256]
     assert oracle.lib.qmo_type_size(9) == 36                        # Q8_1: d, s, 32 int8
     assert oracle.row_size(Q4_K, 4096) == 4096 // 256 * 144
     assert oracle.lib.qmo_type_size(15) == 292
