@@ -31,6 +31,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -64,6 +65,8 @@ struct mi355x_device_ctx {
     // in front of every split input and behind every graph (six calls per generated token, five of them with nothing queued since the
     // last one); a wait on an idle stream still costs ~9 us of host time (round 3, GGML_MI355X_TIMING), so those return at once
     std::atomic<uint64_t> enq{0}, enq_synced{0};
+    // prompt batches already run in QMM_PREC_BF16 (GGML_MI355X_PREC=bf16, or a first prompt met a weight block beyond the f16 range)
+    bool        prefill_bf16 = [] { const char * e = getenv("GGML_MI355X_PREC"); return e && (!strcmp(e, "bf16") || !strcmp(e, "0")); }();
 };
 
 // SURVEY 8f-2, weight repack: Q4_0 / Q8_0 / Q6_K weight tensors are re-laid into aligned planes (qmm_repack_rows) the first time
@@ -77,6 +80,7 @@ struct mi355x_buffer_ctx {
     void *              base;
     std::mutex                          mu;
     std::map<const char *, planar_rec>  planar;     // by the tensor's first byte
+    std::set<const char *>              wire_only;  // weights that went back to wire layout for good (a view cut their rows)
 };
 
 struct mi355x_backend_ctx {
@@ -167,8 +171,15 @@ void planar_release(mi355x_buffer_ctx * bc, const char * p, size_t size, bool ov
         if (t0 < p + size && p < t0 + r.bytes) {
             const bool covered = overwritten && p <= t0 && t0 + r.bytes <= p + size;
             if (!covered) {
-                if (qmm_repack_rows(bc->dev->qmm, r.wire_type, (void *) t0, r.row_bytes, r.rows, r.K, 0, stream) || qmm_synchronize(bc->dev->qmm, stream))
+                // the buffer-level callers pass the NULL stream, and the device's own stream is non-blocking: launches queued
+                // there that still read the planar rows (or the to-planar repack itself) must be through before the rows are re-laid
+                void * own = qmm_stream(bc->dev->qmm);
+                if (stream != own && qmm_synchronize(bc->dev->qmm, own)) GGML_LOG_ERROR("MI355X: %s\n", qmm_last_error());
+                if (qmm_repack_rows(bc->dev->qmm, r.wire_type, (void *) t0, r.row_bytes, r.rows, r.K, 0, stream))
                     GGML_ABORT("MI355X: converting a planar weight back to wire layout failed: %s", qmm_last_error());
+                // (a failing synchronize here reports conditions of OTHER work as well: a non-finite prefill, a bad expert id; they are
+                // logged where they belong, not turned into an abort of this copy)
+                if (qmm_synchronize(bc->dev->qmm, stream)) GGML_LOG_ERROR("MI355X: %s\n", qmm_last_error());
             }
             it = bc->planar.erase(it);
         } else {
@@ -191,18 +202,33 @@ int dev_type(const ggml_tensor * t) {
     std::lock_guard<std::mutex> lock(bc->mu);
     auto it = bc->planar.find((const char *) root->data);
     if (it == bc->planar.end()) return (int) t->type;
-    GGML_ASSERT(t->ne[0] == root->ne[0] && t->nb[1] == root->nb[1] && "a view that cuts rows of a planar weight");
+    if (t->ne[0] != root->ne[0] || t->nb[1] != root->nb[1]) {
+        // a view that cuts rows of a planar weight (nothing in llama.cpp builds one; ADVICE r2: no abort): the weight goes back to wire
+        // layout for good and the view is served from that
+        GGML_LOG_WARN("MI355X: %s views part of the rows of %s; the weight returns to wire layout\n", t->name, root->name);
+        const planar_rec r = it->second;
+        void * own = qmm_stream(bc->dev->qmm);
+        if (qmm_repack_rows(bc->dev->qmm, r.wire_type, (void *) it->first, r.row_bytes, r.rows, r.K, 0, own))
+            GGML_ABORT("MI355X: converting a planar weight back to wire layout failed: %s", qmm_last_error());
+        bc->wire_only.insert(it->first);
+        bc->planar.erase(it);
+        return (int) t->type;
+    }
     return (int) t->type + 100;
 }
 // first use as a MUL_MAT / MUL_MAT_ID weight: convert the whole (root) tensor, on the compute stream, in front of the launch
 int weight_type(mi355x_backend_ctx * ctx, const ggml_tensor * t) {
     const ggml_tensor * root = t->view_src ? t->view_src : t;
     mi355x_buffer_ctx * bc = GGML_MI355X_REPACK() ? our_buffer_ctx(root) : nullptr;
+    // weights only: a quantized tensor in a compute or KV buffer (a Q8_0 K cache) is rewritten all the time; re-laying it
+    // in place behind its writers' backs would corrupt it
+    if (bc && root->buffer && root->buffer->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS) bc = nullptr;
     const int pt = bc ? qmm_planar_type((int) root->type, root->ne[0], (int64_t) root->nb[1]) : 0;
     if (!pt || !ggml_is_contiguous(root) || (uintptr_t) root->data % 16 || t->ne[0] != root->ne[0] || t->nb[1] != root->nb[1]) return dev_type(t);
     {
         std::lock_guard<std::mutex> lock(bc->mu);
         if (bc->planar.count((const char *) root->data)) return pt;
+        if (bc->wire_only.count((const char *) root->data)) return (int) t->type;
         const int64_t rows = ggml_nrows(root);
         if (qmm_repack_rows(ctx->dev->qmm, (int) root->type, root->data, (int64_t) root->nb[1], rows, root->ne[0], 1, qmm_stream(ctx->dev->qmm))) {
             GGML_LOG_WARN("MI355X: repack of %s refused (%s); it stays in wire layout\n", root->name, qmm_last_error());
@@ -1838,8 +1864,32 @@ static double wall_us() {
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+static enum ggml_status graph_compute_once(ggml_backend_t backend, struct ggml_cgraph * cgraph, bool * f16_overflow);
+
+// a prompt whose f16-mode prefill met a weight block beyond the f16 range (valid GGUF bits: |d * sc * q| >= 65504) used to fail
+// llama_decode although token generation on the same model works (the mat-vec path dots integers).  The library reports it at the
+// graph's synchronize; the graph is then issued once more in QMM_PREC_BF16, which has f32's range (NMSE <= 5e-4 against the CPU, the
+// reference's own bar), and the device stays in that mode: a model with such a block needs it for every prompt.  Re-issuing is safe:
+// a graph's leaves and inputs are never reused by ggml-alloc, every other tensor is rewritten by its node, KV-cache stores rewrite the
+// same rows with the same values.
 enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgraph * cgraph) {
+    bool overflow = false;
+    enum ggml_status st = graph_compute_once(backend, cgraph, &overflow);
+    if (st != GGML_STATUS_SUCCESS && overflow) {
+        auto * ctx = (mi355x_backend_ctx *) backend->context;
+        GGML_LOG_WARN("MI355X: a weight block of this model exceeds the f16 range; prompt batches on %s run in bf16 from here on (GGML_MI355X_PREC=bf16 avoids the first attempt)\n",
+                      ctx->name.c_str());
+        if (qmm_set_precision(ctx->dev->qmm, QMM_PREC_BF16)) return st;
+        ctx->dev->prefill_bf16 = true;
+        ctx->readers_sig = 0;                                   // (nothing cached depends on the mode; start the attempt from a clean analysis all the same)
+        st = graph_compute_once(backend, cgraph, &overflow);
+    }
+    return st;
+}
+
+static enum ggml_status graph_compute_once(ggml_backend_t backend, struct ggml_cgraph * cgraph, bool * f16_overflow) {
     auto * ctx = (mi355x_backend_ctx *) backend->context;
+    *f16_overflow = false;
     const bool timing = GGML_MI355X_TIMING();
     const uint64_t queued = ++ctx->dev->enq;
     const double t_enter = timing ? wall_us() : 0;
@@ -1961,7 +2011,11 @@ enum ggml_status backend_graph_compute(ggml_backend_t backend, struct ggml_cgrap
     if (timing && ctx->ev_t0 && ctx->ev_t1) qmm_event_record(ctx->dev->qmm, ctx->ev_t1, qmm_stream(ctx->dev->qmm));
     const double t_issued = timing ? wall_us() : 0;
     // the scheduler reads results right after graph_compute/synchronize; a bad expert id surfaces here
-    if (qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm))) {
+    if (const int rc = qmm_synchronize(ctx->dev->qmm, qmm_stream(ctx->dev->qmm))) {
+        if (rc == QMM_EUNSUPPORTED && strstr(qmm_last_error(), "non-finite") && !ctx->dev->prefill_bf16) {
+            *f16_overflow = true;                               // the caller re-issues the graph in bf16
+            return GGML_STATUS_FAILED;
+        }
         GGML_LOG_ERROR("MI355X graph_compute: %s\n", qmm_last_error());
         return GGML_STATUS_FAILED;
     }

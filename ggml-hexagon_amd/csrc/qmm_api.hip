@@ -730,9 +730,9 @@ static int mul_mat_group_impl(qmm_ctx * c, const qmm_weight * ws, int nw, int64_
         if (ws[i].M == 0) { ++i; continue; }
         int j = i + 1;
         while (j < nw && j - i < 4 && ws[j].type == ws[i].type && ws[j].M > 0) ++j;
-        const int key = mfma_prep_key(c, ws[i].type, N, ws[i].M);
+        const int key = mfma_prep_key(c, ws[i].type, N, ws[i].M, K);
         bool same_key = true;
-        for (int k = i + 1; k < j; ++k) same_key = same_key && mfma_prep_key(c, ws[k].type, N, ws[k].M) == key;
+        for (int k = i + 1; k < j; ++k) same_key = same_key && mfma_prep_key(c, ws[k].type, N, ws[k].M, K) == key;
         if (!same_key) j = i + 1;
         if (nruns == (int) (sizeof(runs) / sizeof(runs[0]))) return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_group: too many runs in one group");
         runs[nruns++] = { i, j, key, 0 };

@@ -231,6 +231,15 @@ int main() {
         for (int where = 0; where <= 8; ++where)
             compare(moe_what[where], N, gpu, cpu, [&](Graph & G, std::mt19937 & rng) { moe_block(G, rng, N, where); });
     }
+    // LAST (it leaves the device in bf16 prefill mode): a prompt batch over a weight whose blocks exceed the f16 range (d * sc * q ~ 1e5:
+    // valid Q4_K bits) must come out right, not fail: the module re-issues the graph in QMM_PREC_BF16
+    compare("prefill over weights beyond the f16 range (bf16 re-issue)", 40, gpu, cpu, [&](Graph & G, std::mt19937 & rng) {
+        ggml_tensor * x = weight(G, rng, GGML_TYPE_F32, E, 40, 1.0f);
+        ggml_tensor * W = weight(G, rng, GGML_TYPE_Q4_K, E, E, 2.0e5f);
+        ggml_tensor * mm = ggml_mul_mat(G.ctx, W, x);  G.fresh(mm);
+        ggml_tensor * fin = ggml_scale(G.ctx, mm, 1.0f);  G.fresh(fin);
+        G.outs = { fin };
+    });
     ggml_backend_free(gpu);
     ggml_backend_free(cpu);
     printf("%d OK, %d FAILED\n", n_ok, n_fail);
