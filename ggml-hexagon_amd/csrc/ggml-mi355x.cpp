@@ -1647,6 +1647,47 @@ int graph_pass::site_moe_combine(int i, ggml_tensor * node, int gop) {
             ok = is_slice(ad->src[1], a + 1) && (a == 0 ? is_slice(ad->src[0], 0) : ad->src[0] == cgraph->nodes[idx[a - 1]]) &&
                  (a == U - 2 || (single_use(ad) && !(ad->flags & GGML_TENSOR_FLAG_OUTPUT)));
         }
+        if (ok && !getenv("GGML_MI355X_MOE_COMBINE_NORM_OFF")) {
+            // Round 3: the residual add, the RMS norm and the norm weight that follow the block in the layer (ffn_moe_out + ffn_inp -> l_out,
+            // then the next attn_norm / result_norm) in the same launch: the next three live nodes must be exactly ADD(last, r),
+            // RMS_NORM(add), MUL(rms, w).  Never written then: the product, the partial sums, the block's output and the un-weighted
+            // norm: each has exactly the readers of the pattern (closed readers: analyze_readers).  Written HERE, U + 2 nodes early,
+            // while other workgroups (one per token) still read the expert rows, the weights and the residual: l_out and the normed row
+            // must be clear of the experts and the weights (another layout) and may sit on the residual only as the very same rows.
+            const ggml_tensor * last = cgraph->nodes[idx[U - 2]];
+            int ja = idx[U - 2] + 1;
+            while (ja < n_nodes && (done[ja] || is_noop(cgraph->nodes[ja]))) ++ja;
+            const ggml_tensor * other = nullptr;
+            if (ja + 2 < n_nodes && single_use(last) && !(last->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                ggml_tensor * add = cgraph->nodes[ja], * rn = cgraph->nodes[ja + 1], * mul = cgraph->nodes[ja + 2];
+                if (add->op == GGML_OP_ADD && (add->src[0] == last || add->src[1] == last) && add->src[0] != add->src[1] && rn->op == GGML_OP_RMS_NORM &&
+                    rn->src[0] == add && single_use(rn) && !(rn->flags & GGML_TENSOR_FLAG_OUTPUT) && fused_pair(rn, mul, &other) == QMM_OP_RMS_NORM_MUL) {
+                    const ggml_tensor * r = add->src[0] == last ? add->src[1] : add->src[0];
+                    const auto clear_of = [&](const ggml_tensor * t) {
+                        return early_write_ok(t, { node->src[0], node->src[1], other }) && (early_write_ok(t, { r }) || early_write_ok(t, { r }, r));
+                    };
+                    // one token = one workgroup, which holds all its inputs in registers before it stores (moe_combine_add_norm_kernel): the
+                    // results may then lie on any input (ggml-alloc does put l_out on the dead router weights and the normed row on the residual)
+                    const bool one = add->ne[1] == 1 && add->ne[2] == 1 && add->ne[3] == 1;
+                    if ((one || (clear_of(add) && clear_of(mul))) && !ranges_overlap(add, mul)) {
+                        const qmm_tensor x = to_qt(node->src[0], ctx), w = to_qt(node->src[1], ctx), qb = to_qt(r, ctx), nw = to_qt(other, ctx), qs = to_qt(add, ctx),
+                                         qd = to_qt(mul, ctx);
+                        if (qmm_moe_combine_add_rms_norm_supported(&x, &w, &qb, &nw, &qs, &qd)) {
+                            float eps;
+                            memcpy(&eps, rn->op_params, sizeof(float));
+                            if (qmm_moe_combine_add_rms_norm(ctx->dev->qmm, &x, &w, &qb, &nw, &qs, &qd, eps, qmm_stream(ctx->dev->qmm))) {
+                                GGML_LOG_ERROR("MI355X MoE combine + ADD + RMS_NORM(%s): %s\n", node->name, qmm_last_error());
+                                return -1;
+                            }
+                            if (dbg()) fprintf(stderr, "fused: moe combine + add + rms_norm (%s)\n", add->name);
+                            for (int a = 0; a < U - 1; ++a) done[idx[a]] = 1;
+                            done[ja] = done[ja + 1] = done[ja + 2] = 1;
+                            return 1;
+                        }
+                    }
+                }
+            }
+        }
         if (ok) {
             const ggml_tensor * last = cgraph->nodes[idx[U - 2]];
             // the launch writes the LAST add's buffer at the MUL's position, while other workgroups still read the experts and the

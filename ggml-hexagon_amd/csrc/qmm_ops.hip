@@ -728,14 +728,8 @@ moe_router_logits_kernel(const char * __restrict__ wgt, const char * __restrict_
 
 // The other end of a mixture-of-experts block (build_moe_ffn, src/llama-graph.cpp:896-911): experts * weights, then the sum over the
 // used experts through 2-D views, as one launch: out[n][c] = ((x[n][0][c] w[n][0] + x[n][1][c] w[n][1]) + ...), in the graph's order.
-__global__ void __launch_bounds__(256)
-moe_combine_kernel(const char * __restrict__ x, const char * __restrict__ w, char * __restrict__ out, const int64_t x_nb1, const int64_t x_nb2,
-                   const int64_t w_nb1, const int64_t w_nb2, const int64_t o_nb1, const int E, const int U) {
-    const int n = blockIdx.y;
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c >= E) return;
-    const char * px = x + (int64_t) n * x_nb2 + (int64_t) c * 4;
-    const char * pw = w + (int64_t) n * w_nb2;
+// (four columns of one token: ((x0 w0) + x1 w1) + ..., shared by moe_combine_kernel and moe_combine_add_norm_kernel)
+__device__ __forceinline__ float4 moe_combine4(const char * __restrict__ px, const char * __restrict__ pw, const int64_t x_nb1, const int64_t w_nb1, const int U) {
     float4 acc = *(const float4 *) px;
     {
         const float w0 = *(const float *) pw;
@@ -746,7 +740,65 @@ moe_combine_kernel(const char * __restrict__ x, const char * __restrict__ w, cha
         const float wu = *(const float *) (pw + (int64_t) u * w_nb1);
         acc.x += v.x * wu; acc.y += v.y * wu; acc.z += v.z * wu; acc.w += v.w * wu;
     }
-    *(float4 *) (out + (int64_t) n * o_nb1 + (int64_t) c * 4) = acc;
+    return acc;
+}
+__global__ void __launch_bounds__(256)
+moe_combine_kernel(const char * __restrict__ x, const char * __restrict__ w, char * __restrict__ out, const int64_t x_nb1, const int64_t x_nb2,
+                   const int64_t w_nb1, const int64_t w_nb2, const int64_t o_nb1, const int E, const int U) {
+    const int n = blockIdx.y;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= E) return;
+    *(float4 *) (out + (int64_t) n * o_nb1 + (int64_t) c * 4) = moe_combine4(x + (int64_t) n * x_nb2 + (int64_t) c * 4, w + (int64_t) n * w_nb2, x_nb1, w_nb1, U);
+}
+
+// The block's tail with what follows it in the layer (round 3): out = combine(x, w) as above, sum = out + b (the residual: l_out),
+// y = rms_norm(sum) * nw (the next attn_norm, or result_norm): moe_combine_kernel's and rms_norm_vec_kernel<true, true, NT>'s arithmetic
+// in that kernel's partition and order of additions, so both results are the two launches' bit for bit.
+template <int NT>
+__global__ void __launch_bounds__(NT)
+moe_combine_add_norm_kernel(const char * __restrict__ x, const char * __restrict__ wts, const char * __restrict__ b, const float * __restrict__ nw,
+                            char * __restrict__ y, char * __restrict__ s, const int64_t x_nb1, const int64_t x_nb2, const int64_t w_nb1, const int64_t w_nb2,
+                            const int64_t b_nb1, const int64_t y_nb1, const int64_t s_nb1, const int E, const int U, const float eps) {
+    __shared__ float red[16];
+    const int n = blockIdx.x;
+    const float4 * pb = (const float4 *) (b + (int64_t) n * b_nb1);
+    float4 *       py = (float4 *) (y + (int64_t) n * y_nb1);
+    float4 *       ps = (float4 *) (s + (int64_t) n * s_nb1);
+    const uint32_t n4 = (uint32_t) E / 4;
+    float4 v[4], wv[4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = threadIdx.x + j * NT;
+        v[j] = i < n4 ? moe_combine4(x + (int64_t) n * x_nb2 + (int64_t) i * 16, wts + (int64_t) n * w_nb2, x_nb1, w_nb1, U) : make_float4(0, 0, 0, 0);
+        wv[j] = i < n4 ? ((const float4 *) nw)[i] : make_float4(0, 0, 0, 0);
+        if (i < n4) {
+            const float4 t = pb[i];
+            v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w;
+        }
+    }
+    // every input of this token is in registers before the first output is stored: with ONE token (one workgroup: token generation) the
+    // two results may therefore lie on ANY of the inputs, which is where ggml-alloc puts them in llama.cpp's graphs (l_out on the
+    // dead router weights, the normed row on the residual); with more tokens the caller keeps them clear of what other workgroups read
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = threadIdx.x + j * NT;
+        if (i < n4) ps[i] = v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    sum = block_reduce<false>(sum, red);
+    const float scale = 1.0f / sqrtf(sum / (float) E + eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = threadIdx.x + j * NT;
+        if (i < n4) {
+            float4 r = make_float4(v[j].x * scale, v[j].y * scale, v[j].z * scale, v[j].w * scale);
+            r.x *= wv[j].x; r.y *= wv[j].y; r.z *= wv[j].z; r.w *= wv[j].w;
+            py[i] = r;
+        }
+    }
 }
 
 // Few outputs with a long K (the MoE router at batch 1: 8 x 4096): one WORKGROUP per dst element, so K is spread over DOT_T = 128
@@ -2233,6 +2285,35 @@ int qmm_moe_combine(qmm_ctx * ctx, const qmm_tensor * x, const qmm_tensor * w, c
     const int E = (int) x->ne[0];
     hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned) ((E / 4 + 255) / 256), (unsigned) x->ne[2]), dim3(256), 0, ctx->s(stream), (const char *) x->data,
                        (const char *) w->data, (char *) out->data, x->nb[1], x->nb[2], w->nb[1], w->nb[2], out->nb[1], E, (int) x->ne[1]);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+int qmm_moe_combine_add_rms_norm_supported(const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * b, const qmm_tensor * nw, const qmm_tensor * sum,
+                                           const qmm_tensor * dst) {
+    if (!b || !nw || !sum || !dst || !qmm_moe_combine_supported(x, w, sum)) return 0;
+    const int64_t E = x->ne[0], N = x->ne[2];
+    if (E > 1024 * 16 || b->type != G_F32 || nw->type != G_F32 || dst->type != G_F32) return 0;
+    for (const qmm_tensor * t : { b, sum, dst })
+        if (t->ne[0] != E || t->ne[1] != N || t->ne[2] != 1 || t->ne[3] != 1 || t->nb[0] != 4 || t->nb[1] % 16 || (uintptr_t) t->data % 16) return 0;
+    return nw->ne[0] == E && nw->ne[1] * nw->ne[2] * nw->ne[3] == 1 && nw->nb[0] == 4 && (uintptr_t) nw->data % 16 == 0 && (uintptr_t) x->data % 16 == 0;
+}
+
+int qmm_moe_combine_add_rms_norm(qmm_ctx * ctx, const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * b, const qmm_tensor * nw, const qmm_tensor * sum,
+                                 const qmm_tensor * dst, float eps, void * stream) {
+    if (!ctx || !qmm_moe_combine_add_rms_norm_supported(x, w, b, nw, sum, dst)) return fail(QMM_EUNSUPPORTED, "qmm_moe_combine_add_rms_norm: operands not supported");
+    if (eps < 0.0f) return fail(QMM_EINVAL, "qmm_moe_combine_add_rms_norm: eps < 0");
+    HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
+    const int E = (int) x->ne[0], N = (int) x->ne[2];
+    const bool wide = N < 256 || E > 256 * 16;              // launch_rms_norm_vec's rule: the same partition as the stand-alone kernel
+    hipStream_t st = ctx->s(stream);
+    if (wide) hipLaunchKernelGGL((moe_combine_add_norm_kernel<1024>), dim3((unsigned) N), dim3(1024), 0, st, (const char *) x->data, (const char *) w->data, (const char *) b->data,
+                                 (const float *) nw->data, (char *) dst->data, (char *) sum->data, x->nb[1], x->nb[2], w->nb[1], w->nb[2], b->nb[1], dst->nb[1], sum->nb[1], E,
+                                 (int) x->ne[1], eps);
+    else      hipLaunchKernelGGL((moe_combine_add_norm_kernel<256>), dim3((unsigned) N), dim3(256), 0, st, (const char *) x->data, (const char *) w->data, (const char *) b->data,
+                                 (const float *) nw->data, (char *) dst->data, (char *) sum->data, x->nb[1], x->nb[2], w->nb[1], w->nb[2], b->nb[1], dst->nb[1], sum->nb[1], E,
+                                 (int) x->ne[1], eps);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }

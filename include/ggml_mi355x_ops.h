@@ -115,6 +115,14 @@ QMM_API int qmm_moe_router_logits(qmm_ctx * ctx, const qmm_tensor * gate_inp, co
  * (ggml_mul by the router weights, then the ggml_add chain over 2-D views, src/llama-graph.cpp:896-911), in the graph's order. */
 QMM_API int qmm_moe_combine_supported(const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * out);
 QMM_API int qmm_moe_combine(qmm_ctx * ctx, const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * out, void * stream);
+/* ... with the residual add and the RMS norm that follow the block in the layer (src/llama-model.cpp:4318-4330, 4216: ffn_moe_out + ffn_inp
+ * -> l_out, then the next attn_norm or result_norm): sum [E, n_tokens] = combine(x, w) + b, dst = rms_norm(sum) * nw [E]; one launch,
+ * both results the bits of qmm_moe_combine followed by qmm_op_add_rms_norm.  With one token (one workgroup) sum and dst may overlap any input
+ * (all inputs are read before the first store); with more tokens they must be clear of x and w, and of b except as the very same rows. */
+QMM_API int qmm_moe_combine_add_rms_norm_supported(const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * b, const qmm_tensor * nw,
+                                                   const qmm_tensor * sum, const qmm_tensor * dst);
+QMM_API int qmm_moe_combine_add_rms_norm(qmm_ctx * ctx, const qmm_tensor * x, const qmm_tensor * w, const qmm_tensor * b, const qmm_tensor * nw,
+                                         const qmm_tensor * sum, const qmm_tensor * dst, float eps, void * stream);
 
 /* qmm_rope_kv_store and qmm_attn_decode as ONE launch for a batch of up to 8 tokens (normal-mode RoPE over the whole head,
  * D <= 128): q [D, H, N] arrives un-roped (q_rope: the ROPE node's descriptor, for its op_params), k_new [D, H_kv, N] and

@@ -124,6 +124,22 @@ static void moe_block(Graph & G, std::mt19937 & rng, int64_t N, int where) {
         else if (i == NU - 1 && where == 5) G.at(out, o_dv);                        // on the weights (8 N bytes at the start of spare2)
         else G.fresh(out);
     }
+    if (where >= 9) {
+        // the layer's tail behind the block (round 3: one launch with the combine): l_out = out + x, rms_norm(l_out) * nw.
+        // 10: l_out on the expert outputs, 11: the normed row exactly on the residual (in place: allowed), 12: the normed row on the
+        // residual one row further, 13: l_out on the expert weights
+        ggml_tensor * nw = weight(G, rng, GGML_TYPE_F32, E, 1, 1.0f);
+        ggml_tensor * lo = ggml_add(G.ctx, out, x);
+        if (where == 10) G.at(lo, o_ex); else if (where == 13) G.at(lo, o_dv); else G.fresh(lo);
+        ggml_tensor * rn = ggml_rms_norm(G.ctx, lo, 1e-5f);                         G.fresh(rn);
+        ggml_tensor * y = ggml_mul(G.ctx, rn, nw);
+        if (where == 11) G.at(y, G.place[0].off); else if (where == 12) G.at(y, G.place[0].off + E * 4); else G.fresh(y);
+        ggml_tensor * f1 = ggml_scale(G.ctx, y, 1.0f);                              G.fresh(f1);
+        // (l_out is read last, so that a normed row placed on the residual does not change what the CPU computes for it)
+        ggml_tensor * f0 = ggml_scale(G.ctx, lo, 1.0f);                             G.fresh(f0);
+        G.outs = { f1, f0 };
+        return;
+    }
     ggml_tensor * fin = ggml_scale(G.ctx, out, 1.0f);                               G.fresh(fin);
     G.outs = { fin };
 }
@@ -227,8 +243,12 @@ int main() {
                                     // round 3: for a few tokens the launch also computes the logits, i.e. reads the block's input while it writes
                                     "argsort ids placed on the router MUL_MAT's src1", "normalised weights (DIV) placed on the router MUL_MAT's src1",
                                     // ... and the expert pair writes silu(gate) * up itself, while src1 is still being staged
-                                    "silu(gate) * up of the experts placed on their src1" };
-        for (int where = 0; where <= 8; ++where)
+                                    "silu(gate) * up of the experts placed on their src1",
+                                    // ... and the combine takes the residual add and the RMS norm behind the block along
+                                    "MoE block + residual add + RMS norm, free placement", "l_out placed on the expert outputs",
+                                    "normed row placed exactly on the residual", "normed row placed on the residual, one row further",
+                                    "l_out placed on the expert weights" };
+        for (int where = 0; where <= 13; ++where)
             compare(moe_what[where], N, gpu, cpu, [&](Graph & G, std::mt19937 & rng) { moe_block(G, rng, N, where); });
     }
     // LAST (it leaves the device in bf16 prefill mode): a prompt batch over a weight whose blocks exceed the f16 range (d * sc * q ~ 1e5:

@@ -401,3 +401,36 @@ def test_moe_combine_one_launch(qmm, n_tok, n_used, e):
         want = want + x[:, u] * w[:, u]
     got = dx.cpu().numpy()[:, 0]
     assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("n_tok,n_used,e", [(1, 2, 4096), (8, 2, 4096), (3, 6, 1024), (300, 2, 2048), (2, 2, 8192)])
+def test_moe_combine_with_residual_add_and_rms_norm_one_launch(qmm, n_tok, n_used, e):
+    """qmm_moe_combine_add_rms_norm (round 3) against qmm_moe_combine followed by qmm_op_add_rms_norm: l_out and the normed row, bit for bit
+    (few rows: the 1024-thread partition; 300 rows: the 256-thread one; 8192 columns: two float4 per thread)"""
+    from ggml_hexagon_amd import capi
+    rng = np.random.default_rng(n_tok * 5 + e)
+    dx = dev(rng.normal(0, 1, (n_tok, n_used, e)).astype(np.float32))
+    dw = dev(rng.uniform(0.1, 0.9, (n_tok, n_used, 1)).astype(np.float32))
+    db = dev(rng.normal(0, 1, (n_tok, e)).astype(np.float32))
+    dn = dev(rng.uniform(0.5, 1.5, (e,)).astype(np.float32))
+    M = capi.QmmTensor.make
+    r = lambda t: capi.C.byref(t)
+    tx, tw = M(F32, [e, n_used, n_tok], data=dx.data_ptr()), M(F32, [1, n_used, n_tok], data=dw.data_ptr())
+    tb, tn = M(F32, [e, n_tok], data=db.data_ptr()), M(F32, [e], data=dn.data_ptr())
+    outs = []
+    for fused in (False, True):
+        tmp = torch.full((n_tok, e), float("nan"), device="cuda")
+        s_, y_ = torch.full((n_tok, e), float("nan"), device="cuda"), torch.full((n_tok, e), float("nan"), device="cuda")
+        ts, ty, tt = M(F32, [e, n_tok], data=s_.data_ptr()), M(F32, [e, n_tok], data=y_.data_ptr()), M(F32, [e, n_tok], data=tmp.data_ptr())
+        if fused:
+            assert qmm.lib.qmm_moe_combine_add_rms_norm_supported(r(tx), r(tw), r(tb), r(tn), r(ts), r(ty))
+            qmm._chk(qmm.lib.qmm_moe_combine_add_rms_norm(qmm.ctx, r(tx), r(tw), r(tb), r(tn), r(ts), r(ty), 1e-5, qmm._stream()))
+        else:
+            qmm._chk(qmm.lib.qmm_moe_combine(qmm.ctx, r(tx), r(tw), r(tt), qmm._stream()))
+            qmm._chk(qmm.lib.qmm_op_add_rms_norm(qmm.ctx, r(tt), r(tb), r(tn), r(ts), r(ty), 1e-5, qmm._stream()))
+        qmm.synchronize()
+        outs.append((s_, y_))
+    assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
+    assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32))
+    want = (dx * dw).sum(dim=1) + db
+    assert torch.allclose(outs[1][0], want, rtol=1e-5, atol=1e-6)
