@@ -52,7 +52,7 @@ static int launch_matvec_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, c
     int blocks = (total + nw - 1) / nw;
     if (blocks > c->cus * c->mv_bpc) blocks = c->cus * c->mv_bpc;
     QMM_TRACE(c, "matvec_kernel<%d,%d,%s>", T, NTOK, group_has_extras(g) ? "true" : "false");
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * WAVE), lds, st, g, x, ldx, K, c->act_mode, g.row_end[g.n - 1]);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * WAVE), lds, st, g, x, ldx, K, c->act_mode | (c->mv_onepass ? 0 : 256), g.row_end[g.n - 1]);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }
@@ -69,7 +69,7 @@ static int launch_kmix_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, con
     int blocks = (total + nw - 1) / nw;
     if (blocks > c->cus * c->mv_bpc) blocks = c->cus * c->mv_bpc;
     QMM_TRACE(c, "matvec_kmix_kernel<%d,%s>", NTOK, group_has_extras(g) ? "true" : "false");
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * WAVE), lds, st, g, x, ldx, K, c->act_mode, total);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * WAVE), lds, st, g, x, ldx, K, c->act_mode | (c->mv_onepass ? 0 : 256), total);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }
@@ -308,6 +308,8 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->r64s = atoi(e);
     e = getenv("GGML_MI355X_PREP_REG");
     if (e) c->prep_reg = atoi(e);
+    e = getenv("GGML_MI355X_MV_ONEPASS");
+    if (e) c->mv_onepass = atoi(e);
     e = getenv("GGML_MI355X_SIDE");
     if (e) c->side_on = atoi(e);
     e = getenv("GGML_MI355X_SPLITK_COMBINE");

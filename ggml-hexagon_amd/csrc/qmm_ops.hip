@@ -73,6 +73,30 @@ template <bool MAX> __device__ __forceinline__ float block_reduce(float v, float
     return r;
 }
 
+// 1 / sqrt(mean of squares + eps) of a row from the threads' partial sums, for the RMS-norm kernels: block_reduce's partial sums and order
+// of additions; with 16 waves (four to a SIMD) the scalar tail (the wave sums out of LDS, two IEEE divisions, a square root: ~150
+// dependent instructions) is run by wave 0 alone and handed over through LDS: run by every wave it cost ~1 us of the ~4.7 us launch
+// (round 3, the same finding as in the mat-vec staging: profiles/tools/ex_times.py).  `red` holds 17 floats.
+template <int NT> __device__ __forceinline__ float rms_scale_block(float sum, float * red, const float ne0, const float eps) {
+    sum = wave_sum(sum);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (NT <= 512) {
+        float r = red[0];
+        for (int i = 1; i < NT / 64; ++i) r += red[i];
+        return 1.0f / sqrtf(r / ne0 + eps);
+    }
+    if (threadIdx.x < 64) {
+        float r = red[0];
+        for (int i = 1; i < NT / 64; ++i) r += red[i];
+        const float sc = 1.0f / sqrtf(r / ne0 + eps);
+        if (threadIdx.x == 0) red[16] = sc;
+    }
+    __syncthreads();
+    return red[16];
+}
+
 // row index -> byte offset of the row in a (possibly broadcast) operand
 __device__ __forceinline__ void row_coords(uint32_t row, uint32_t ne1, uint32_t ne2, uint32_t & i1, uint32_t & i2, uint32_t & i3) {
     i1 = row % ne1;
@@ -215,7 +239,7 @@ template <bool MUL, bool ADD, int NT>
 __global__ void __launch_bounds__(NT)
 rms_norm_vec_kernel(const char * __restrict__ x, const char * __restrict__ b, const float * __restrict__ w, char * __restrict__ y,
                     char * __restrict__ s, const Shape sx, const Shape sb, const Shape sy, const Shape ss, const float eps) {
-    __shared__ float red[16];
+    __shared__ float red[17];
     uint32_t i1, i2, i3;
     row_coords(blockIdx.x, (uint32_t) sx.ne[1], (uint32_t) sx.ne[2], i1, i2, i3);
     const float4 * px = (const float4 *) (x + i1 * sx.nb[1] + i2 * sx.nb[2] + i3 * sx.nb[3]);
@@ -244,8 +268,7 @@ rms_norm_vec_kernel(const char * __restrict__ x, const char * __restrict__ b, co
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) sum += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-    sum = block_reduce<false>(sum, red);
-    const float scale = 1.0f / sqrtf(sum / (float) sx.ne[0] + eps);
+    const float scale = rms_scale_block<NT>(sum, red, (float) sx.ne[0], eps);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t i = threadIdx.x + j * NT;
@@ -759,7 +782,7 @@ __global__ void __launch_bounds__(NT)
 moe_combine_add_norm_kernel(const char * __restrict__ x, const char * __restrict__ wts, const char * __restrict__ b, const float * __restrict__ nw,
                             char * __restrict__ y, char * __restrict__ s, const int64_t x_nb1, const int64_t x_nb2, const int64_t w_nb1, const int64_t w_nb2,
                             const int64_t b_nb1, const int64_t y_nb1, const int64_t s_nb1, const int E, const int U, const float eps) {
-    __shared__ float red[16];
+    __shared__ float red[17];
     const int n = blockIdx.x;
     const float4 * pb = (const float4 *) (b + (int64_t) n * b_nb1);
     float4 *       py = (float4 *) (y + (int64_t) n * y_nb1);
@@ -788,8 +811,7 @@ moe_combine_add_norm_kernel(const char * __restrict__ x, const char * __restrict
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) sum += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-    sum = block_reduce<false>(sum, red);
-    const float scale = 1.0f / sqrtf(sum / (float) E + eps);
+    const float scale = rms_scale_block<NT>(sum, red, (float) E, eps);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t i = threadIdx.x + j * NT;
