@@ -1140,7 +1140,7 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
     }
 }
 
-// Short caches (n_kv <= 512, D and Dv <= 128: token generation inside llama.cpp's first windows, where the launch is a chain of
+// Short caches (n_kv <= 1024 in one or two halves of 512 columns, D and Dv <= 128: token generation inside llama.cpp's first windows, where the launch is a chain of
 // latencies: 64 KB of K and V per head).  Round 3 stamps of the kernel above at n_kv = 256 (profiles/tools/attn_dev.hip): 2.9 us until
 // the new rows are roped and in LDS, 0.9 us scores, 0.8 us softmax, 2.6 us for the V product (its loads requested behind the second
 // barrier), 7.9 us in the kernel for a 10.5 us slot.  This one
@@ -1153,7 +1153,7 @@ attn_decode_kernel(const AttnArgs g, const AttnFresh f) {
 //   * folds the eight V-row sums of a wave into one register with v_permlane32_swap / v_permlane16_swap before the DPP steps
 //     (20 instructions instead of 8 wave_sums).
 // Same arithmetic as the CPU chain (q, p rounded to f16, f32 accumulation, soft_max_kernel's max / exp / sum); sums in another order.
-template <int D, bool FRESH, bool W256>
+template <int D, bool FRESH, int WIDTH>
 __global__ void __launch_bounds__(1024)
 attn_decode_short_kernel(const AttnArgs g, const AttnFresh f) {
     extern __shared__ float sc[];       // n_kv scores | n_kv exponentials [FRESH: | q row f16 (D halves, D floats reserved) | new K rows f16 | new V rows f16]
@@ -1166,8 +1166,10 @@ attn_decode_short_kernel(const AttnArgs g, const AttnFresh f) {
     const int h = blockIdx.x, n = blockIdx.y, hk = h / g.gqa;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l8 = tid & 7, grp = tid >> 3;
     constexpr int CH = D / 8, NV = CH / 8, HP = D / 2;
-    constexpr int NR = W256 ? 2 : 4;                    // K rows per 8-lane group (n_kv <= 256: two)
-    constexpr int CPL = W256 ? 4 : 8;                   // cache columns per lane in the softmax and the V product
+    static_assert(WIDTH == 256 || WIDTH == 512 || WIDTH == 1024, "cache columns this instantiation covers");
+    constexpr int NR = WIDTH == 256 ? 2 : 4;            // K rows per 8-lane group and trip (n_kv <= 256: two)
+    constexpr int CPL = WIDTH == 256 ? 4 : 8;           // cache columns per lane and trip in the softmax and the V product
+    constexpr int TRIPS = WIDTH == 1024 ? 2 : 1;        // n_kv <= 1024: the cache in two halves of 512 columns through the same registers
     typedef _Float16 hcol __attribute__((ext_vector_type(CPL)));
     float *    ex   = sc + g.n_kv;
     _Float16 * qs   = reinterpret_cast<_Float16 *>(ex + g.n_kv);
@@ -1285,20 +1287,47 @@ attn_decode_short_kernel(const AttnArgs g, const AttnFresh f) {
     }
     // ---- scores
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int j = grp + 128 * r;
-        if (FRESH && (unsigned) (j - f.j0) < (unsigned) f.N) {
+    for (int trip = 0; trip < TRIPS; ++trip) {
+        if (trip > 0) {                                 // the second half's rows into the registers the first half has released
+            const float * pm = (const float *) (g.mask + (int64_t) n * g.m_nb1);
+            const char *  pk = g.k + (int64_t) hk * g.k_nb2 + (int64_t) l8 * CH * 2;
 #pragma unroll
-            for (int c = 0; c < NV; ++c) kv[r][c] = *(const h16x8 *) &knew[(j - f.j0) * D + l8 * CH + c * 8];
+            for (int r = 0; r < NR; ++r) {
+                const int j = 512 * trip + grp + 128 * r, jc = j < g.n_kv ? j : g.n_kv - 1;
+                const h16x8 * row = (const h16x8 *) (pk + (int64_t) jc * g.k_nb1);
+#pragma unroll
+                for (int c = 0; c < NV; ++c) kv[r][c] = row[c];
+                mk[r] = pm[jc];
+            }
         }
-        float s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < NV; ++c)
+        for (int r = 0; r < NR; ++r) {
+            const int j = 512 * trip + grp + 128 * r;
+            if (FRESH && (unsigned) (j - f.j0) < (unsigned) f.N) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += (float) kv[r][c][e] * (float) qh[c * 8 + e];
-        s = sum8(s);
-        s = s * g.scale + mk[r];
-        if (j < g.n_kv && l8 == 0) sc[j] = s;
+                for (int c = 0; c < NV; ++c) kv[r][c] = *(const h16x8 *) &knew[(j - f.j0) * D + l8 * CH + c * 8];
+            }
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float) kv[r][c][e] * (float) qh[c * 8 + e];
+            s = sum8(s);
+            s = s * g.scale + mk[r];
+            if (j < g.n_kv && l8 == 0) sc[j] = s;
+        }
+    }
+    // the second half's V rows are requested here (the K rows' registers are free), in front of the softmax arithmetic
+    hcol vv2[8];
+    const int jl2 = 512 + jl;
+    const bool live2 = TRIPS > 1 && jl2 < g.n_kv;
+    if (TRIPS > 1) {
+        const char * pv = g.v + (int64_t) hk * g.v_nb2 + (int64_t) (live2 ? jl2 : 0) * 2;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int d = wave + 16 * r < g.Dv ? wave + 16 * r : 0;
+            vv2[r] = *(const hcol *) (pv + (int64_t) d * g.v_nb1);
+        }
     }
     ATTN_STAMP(3);
     __syncthreads();
@@ -1306,30 +1335,40 @@ attn_decode_short_kernel(const AttnArgs g, const AttnFresh f) {
     // ---- softmax: every wave takes the maximum for itself, thread j the exponential of column j
     float m = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < CPL; e += 4) {
-        const float4 a = live ? *(const float4 *) &sc[jl + e] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        m = fmaxf(m, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+    for (int trip = 0; trip < TRIPS; ++trip) {
+        const int jt = 512 * trip + jl;
+#pragma unroll
+        for (int e = 0; e < CPL; e += 4) {
+            const float4 a = jt < g.n_kv ? *(const float4 *) &sc[jt + e] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            m = fmaxf(m, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+        }
     }
     m = wave_max(m);
     if (tid < g.n_kv) ex[tid] = expf(sc[tid] - m);
     __syncthreads();
-    float e8[CPL];
-#pragma unroll
-    for (int e = 0; e < CPL; e += 4) {
-        const float4 a = live ? *(const float4 *) &ex[jl + e] : make_float4(0.f, 0.f, 0.f, 0.f);
-        e8[e] = a.x; e8[e + 1] = a.y; e8[e + 2] = a.z; e8[e + 3] = a.w;
-    }
+    float e8[TRIPS][CPL];
     float sum = 0.0f;
 #pragma unroll
-    for (int e = 0; e < CPL; ++e) sum += e8[e];
+    for (int trip = 0; trip < TRIPS; ++trip) {
+        const int jt = 512 * trip + jl;
+#pragma unroll
+        for (int e = 0; e < CPL; e += 4) {
+            const float4 a = jt < g.n_kv ? *(const float4 *) &ex[jt + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            e8[trip][e] = a.x; e8[trip][e + 1] = a.y; e8[trip][e + 2] = a.z; e8[trip][e + 3] = a.w;
+        }
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) sum += e8[trip][e];
+    }
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
-    _Float16 pr[CPL];
+    _Float16 pr[TRIPS][CPL];
 #pragma unroll
-    for (int e = 0; e < CPL; ++e) {                     // the batch's own positions: column weight 0, their rows come from LDS below
-        const bool fresh = FRESH && (unsigned) (jl + e - f.j0) < (unsigned) f.N;
-        pr[e] = fresh ? (_Float16) 0.0f : (_Float16) (e8[e] * inv);
-    }
+    for (int trip = 0; trip < TRIPS; ++trip)
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {                 // the batch's own positions: column weight 0, their rows come from LDS below
+            const bool fresh = FRESH && (unsigned) (512 * trip + jl + e - f.j0) < (unsigned) f.N;
+            pr[trip][e] = fresh ? (_Float16) 0.0f : (_Float16) (e8[trip][e] * inv);
+        }
     ATTN_STAMP(5);
     // ---- V product: eight rows per wave, their 64 partial sums each folded pairwise into one register
     float acc[8];
@@ -1337,7 +1376,11 @@ attn_decode_short_kernel(const AttnArgs g, const AttnFresh f) {
     for (int r = 0; r < 8; ++r) {
         acc[r] = 0.0f;
 #pragma unroll
-        for (int e = 0; e < CPL; ++e) acc[r] += (float) vv[r][e] * (float) pr[e];
+        for (int e = 0; e < CPL; ++e) acc[r] += (float) vv[r][e] * (float) pr[0][e];
+        if (TRIPS > 1) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) acc[r] += (float) vv2[r][e] * (float) pr[TRIPS - 1][e];
+        }
     }
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     float t4[4], t2[2];
@@ -2076,11 +2119,13 @@ int qmm_attn_decode(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * k, c
         return QMM_OK;
     }
     const AttnFresh none{};
-    if (attn_short_on() && g.n_kv <= 512 && g.D <= 128 && g.Dv <= 128) {
+    if (attn_short_on() && g.n_kv <= 1024 && g.D <= 128 && g.Dv <= 128) {
         const size_t lds2 = (size_t) g.n_kv * 8;
-        const bool w256 = g.n_kv <= 256;
-        if (g.D == 64) hipLaunchKernelGGL((w256 ? attn_decode_short_kernel<64, false, true> : attn_decode_short_kernel<64, false, false>), grid, dim3(1024), lds2, st, g, none);
-        else           hipLaunchKernelGGL((w256 ? attn_decode_short_kernel<128, false, true> : attn_decode_short_kernel<128, false, false>), grid, dim3(1024), lds2, st, g, none);
+        const int w = g.n_kv <= 256 ? 0 : g.n_kv <= 512 ? 1 : 2;
+        auto k64  = w == 0 ? attn_decode_short_kernel<64, false, 256> : w == 1 ? attn_decode_short_kernel<64, false, 512> : attn_decode_short_kernel<64, false, 1024>;
+        auto k128 = w == 0 ? attn_decode_short_kernel<128, false, 256> : w == 1 ? attn_decode_short_kernel<128, false, 512> : attn_decode_short_kernel<128, false, 1024>;
+        if (g.D == 64) hipLaunchKernelGGL(k64, grid, dim3(1024), lds2, st, g, none);
+        else           hipLaunchKernelGGL(k128, grid, dim3(1024), lds2, st, g, none);
         HIP_TRY(hipGetLastError());
         return QMM_OK;
     }
@@ -2224,11 +2269,13 @@ int qmm_attn_decode_rope(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor *
     const dim3 grid((unsigned) g.H, (unsigned) f.N);
     const size_t lds = (size_t) g.n_kv * 4 + (size_t) g.D * 4 + (size_t) f.N * (g.D + g.Dv) * 2;
     hipStream_t st = ctx->s(stream);
-    if (attn_short_on() && g.n_kv <= 512 && g.Dv <= 128) {             // (D <= 128: qmm_attn_decode_rope_supported)
+    if (attn_short_on() && g.n_kv <= 1024 && g.Dv <= 128) {            // (D <= 128: qmm_attn_decode_rope_supported)
         const size_t lds2 = lds + (size_t) g.n_kv * 4;
-        const bool w256 = g.n_kv <= 256;
-        if (g.D == 64) hipLaunchKernelGGL((w256 ? attn_decode_short_kernel<64, true, true> : attn_decode_short_kernel<64, true, false>), grid, dim3(1024), lds2, st, g, f);
-        else           hipLaunchKernelGGL((w256 ? attn_decode_short_kernel<128, true, true> : attn_decode_short_kernel<128, true, false>), grid, dim3(1024), lds2, st, g, f);
+        const int w = g.n_kv <= 256 ? 0 : g.n_kv <= 512 ? 1 : 2;
+        auto k64  = w == 0 ? attn_decode_short_kernel<64, true, 256> : w == 1 ? attn_decode_short_kernel<64, true, 512> : attn_decode_short_kernel<64, true, 1024>;
+        auto k128 = w == 0 ? attn_decode_short_kernel<128, true, 256> : w == 1 ? attn_decode_short_kernel<128, true, 512> : attn_decode_short_kernel<128, true, 1024>;
+        if (g.D == 64) hipLaunchKernelGGL(k64, grid, dim3(1024), lds2, st, g, f);
+        else           hipLaunchKernelGGL(k128, grid, dim3(1024), lds2, st, g, f);
         HIP_TRY(hipGetLastError());
         return QMM_OK;
     }

@@ -25,7 +25,7 @@ __global__ void producer_kernel(float * q, float * k, float * v, int nq, int nk,
 
 int main(int argc, char ** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
-    const int n_kv = argc > 1 ? atoi(argv[1]) : 256, H = 32, Hk = 8, D = 128, N = 1, j0 = n_kv / 2, n_ctx = 1024;
+    const int n_kv = argc > 1 ? atoi(argv[1]) : 256, H = 32, Hk = 8, D = 128, N = 1, j0 = argc > 2 ? atoi(argv[2]) : n_kv / 2, n_ctx = 1024;
     float * q, * kraw, * vraw, * mask, * out;
     _Float16 * kc, * vc;
     int32_t * pos;
@@ -60,7 +60,7 @@ int main(int argc, char ** argv) {
     int which = 1;                                      // 0: attn_decode_kernel (general), 1: attn_decode_short_kernel
     auto launch = [&](float seed) {
         hipLaunchKernelGGL(producer_kernel, dim3(16), dim3(256), 0, 0, q, kraw, vraw, H * D, Hk * D, seed);
-        if (which) hipLaunchKernelGGL((n_kv <= 256 ? attn_decode_short_kernel<128, true, true> : attn_decode_short_kernel<128, true, false>), dim3(H, N), dim3(1024), lds + (size_t) n_kv * 4, 0, g, f);
+        if (which) hipLaunchKernelGGL((n_kv <= 256 ? attn_decode_short_kernel<128, true, 256> : n_kv <= 512 ? attn_decode_short_kernel<128, true, 512> : attn_decode_short_kernel<128, true, 1024>), dim3(H, N), dim3(1024), lds + (size_t) n_kv * 4, 0, g, f);
         else       hipLaunchKernelGGL((attn_decode_kernel<128, true>), dim3(H, N), dim3(1024), lds, 0, g, f);
     };
     // parity of the two kernels: output row and the stored cache rows
