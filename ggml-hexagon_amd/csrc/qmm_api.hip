@@ -308,6 +308,8 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->r64s = atoi(e);
     e = getenv("GGML_MI355X_PREP_REG");
     if (e) c->prep_reg = atoi(e);
+    e = getenv("GGML_MI355X_REGB_Q23");
+    if (e) c->regb_q23 = atoi(e) != 0;
     e = getenv("GGML_MI355X_MV_ONEPASS");
     if (e) c->mv_onepass = atoi(e);
     e = getenv("GGML_MI355X_SIDE");

@@ -53,6 +53,7 @@ struct qmm_ctx {
     int         r64s = 1;            // ... with the K-step's instruction stream placed by hand (mfma_r64s_q4k_kernel, qmm_mfma_r64s.hiph) where the 256 x 256 r64 kernel would run (GGML_MI355X_R64S=0: the compiler-scheduled kernel)
     int         mv_onepass = 1;      // GGML_MI355X_MV_ONEPASS=0: fused-norm mat-vecs stage through stage_rms_norm + quantize_rows again (A/B runs)
     int         prep_reg = 1;        // GGML_MI355X_PREP_REG=0: prep_act_kernel (LDS staging) for Q8_K rows too (A/B runs, parity tests)
+    int         regb_q23 = 1;        // GGML_MI355X_REGB_Q23=0: Q2_K / Q3_K prefill on the LDS-tile kernel again (A/B runs)
     int         splitk = 1;          // split K over workgroups when a MUL_MAT has too few tiles (GGML_MI355X_SPLITK=0: off)
     // chains (qmm_chain.hiph): while recording, one-token MUL_MAT groups are collected instead of launched
     int         chain_enabled = 1;   // GGML_MI355X_CHAIN=0: qmm_chain_begin records nothing, every group is its own launch

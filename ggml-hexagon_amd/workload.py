@@ -11,7 +11,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 
-from .synth import IQ4_XS, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, row_size
+from .synth import IQ4_XS, Q2_K, Q3_K, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0, row_size
 
 
 @dataclass
@@ -91,6 +91,15 @@ def _llama(name, n_layer, n_embd, n_ff, n_head, n_head_kv, n_vocab, recipe, n_ex
                 tv = Q5_K
             if i < n_layer // 8:
                 td = Q5_K
+        elif recipe == "q3_k_m":                     # llama-quant.cpp:228-230 (attn_v), :279-283 (ffn_down), :326 (attn_output)
+            tq = tk = tg = Q3_K
+            tv = Q5_K if i < 2 else Q4_K
+            td = Q5_K if i < n_layer // 16 else Q4_K
+            to = Q4_K
+        elif recipe == "q2_k":                       # llama-quant.cpp:213-215 (attn_v), :272 (ffn_down), :324 (attn_output)
+            tq = tk = tg = Q2_K
+            tv = Q4_K if n_head // n_head_kv >= 4 else Q3_K
+            td = to = Q3_K
         else:                                        # q4_k_m
             tq = tk = to = tg = Q4_K
             tv = td = Q6_K if more else Q4_K
@@ -122,8 +131,10 @@ WORKLOADS = {
     "llama3-70b-q4_k_m":  lambda: _llama("llama3-70b-q4_k_m", 80, 8192, 28672, 64, 8, 128256, "q4_k_m"),
     "mixtral-8x7b-q4_k_m": lambda: _llama("mixtral-8x7b-q4_k_m", 32, 4096, 14336, 32, 8, 32000, "q4_k_m", 8, 2),
     "synth-7b-q4_k":      lambda: _llama("synth-7b-q4_k", 32, 4096, 11008, 32, 32, 32000, "q4_k"),
-    # not a BASELINE config: SURVEY 8f-4's last weight format on the llama3-8b shapes (`bench.py --workload llama3-8b-iq4_xs`)
+    # not BASELINE configs: other weight formats on the llama3-8b shapes (`bench.py --workload llama3-8b-iq4_xs`)
     "llama3-8b-iq4_xs":   lambda: _llama("llama3-8b-iq4_xs", 32, 4096, 14336, 32, 8, 128256, "iq4_xs"),
+    "llama3-8b-q3_k_m":   lambda: _llama("llama3-8b-q3_k_m", 32, 4096, 14336, 32, 8, 128256, "q3_k_m"),
+    "llama3-8b-q2_k":     lambda: _llama("llama3-8b-q2_k", 32, 4096, 14336, 32, 8, 128256, "q2_k"),
 }
 
 
