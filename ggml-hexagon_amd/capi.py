@@ -26,7 +26,7 @@ EXPORTS = [
 # include/ggml_mi355x_ops.h: the glue ops of a transformer layer
 OPS_EXPORTS = [
     "qmm_op_supported", "qmm_op_compute", "qmm_op_add_rms_norm_supported", "qmm_op_add_rms_norm",
-    "qmm_attn_decode_supported", "qmm_attn_decode", "qmm_attn_prefill_supported", "qmm_attn_prefill", "qmm_rope_kv_store_supported", "qmm_rope_kv_store", "qmm_attn_decode_rope_supported", "qmm_attn_decode_rope", "qmm_moe_router_supported", "qmm_moe_router", "qmm_moe_router_logits_supported", "qmm_moe_router_logits", "qmm_moe_combine_supported", "qmm_moe_combine", "qmm_moe_combine_add_rms_norm_supported", "qmm_moe_combine_add_rms_norm",
+    "qmm_attn_decode_supported", "qmm_attn_decode", "qmm_attn_prefill_supported", "qmm_attn_prefill", "qmm_rope_kv_store_supported", "qmm_rope_kv_store", "qmm_attn_decode_rope_supported", "qmm_attn_decode_rope", "qmm_moe_router_supported", "qmm_moe_router", "qmm_moe_router_logits_supported", "qmm_moe_router_logits", "qmm_moe_router_logits_norm_supported", "qmm_moe_router_logits_norm", "qmm_moe_combine_supported", "qmm_moe_combine", "qmm_moe_combine_add_rms_norm_supported", "qmm_moe_combine_add_rms_norm",
 ]
 
 
@@ -121,6 +121,8 @@ def load_library() -> C.CDLL:
     lib.qmm_moe_combine_add_rms_norm.argtypes = [v, P, P, P, P, P, P, C.c_float, v]
     lib.qmm_moe_router.argtypes = [v, P, P, P, i64, i32, v]
     lib.qmm_moe_router_logits.argtypes = [v, P, P, P, P, P, i64, i32, v]
+    lib.qmm_moe_router_logits_norm_supported.argtypes = [P, P, P, P, P, P, P, i64]
+    lib.qmm_moe_router_logits_norm.argtypes = [v, P, P, P, C.c_float, P, P, P, P, i64, i32, v]
     lib.qmm_rope_kv_store.argtypes = [v, P, P, P, P, P, P, P, P, v]
     lib.qmm_attn_decode_rope.argtypes = [v, P, P, P, P, P, P, P, P, P, P, P, P, C.c_float, i64, v]
     lib.qmm_mul_mat_id.argtypes = [v, i32, v, i64, i64, i64, i64, i64, v, i64, i64, i64, v, i64, i64, i64, v, i64, i64, v]

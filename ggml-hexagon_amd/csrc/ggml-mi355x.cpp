@@ -1716,6 +1716,21 @@ int graph_pass::site_moe_router(int i, ggml_tensor * node, int gop) {
     // changes for any other reader; the ids and the weights are written one node earlier than before, now also beside the reads of
     // the MUL_MAT's src1, which joins the operands they must stay clear of
     ggml_tensor * lgt = nullptr;
+    // ... and entered two nodes before that, at the RMS norm whose product with ffn_norm's weights is the logits' src1 (the MoE branch of
+    // the layer, src/llama-model.cpp:4301-4305), the launch forms the normed row too and stores it for the expert MUL_MAT_IDs
+    // (qmm_moe_router_logits_norm): the separate norm launch (4.75 us of a Mixtral layer's ~84) is gone
+    ggml_tensor * nrm = nullptr, * nmul = nullptr;
+    const ggml_tensor * nwgt = nullptr;
+    int i_nmul = -1, i_lgt = -1;
+    if (node->op == GGML_OP_RMS_NORM && i + 2 < n_nodes && node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 && single_use(node) && !GGML_MI355X_FUSE_OFF() &&
+        !getenv("GGML_MI355X_ROUTER_NORM_OFF") && !getenv("GGML_MI355X_ROUTER_LOGITS_OFF")) {
+        ggml_tensor * m = cgraph->nodes[i + 1], * t = cgraph->nodes[i + 2];
+        if (done[i + 1] || done[i + 2] || fused_pair(node, m, &nwgt) != QMM_OP_RMS_NORM_MUL) return 0;
+        if (t->op != GGML_OP_MUL_MAT || t->src[1] != m || (m->flags & GGML_TENSOR_FLAG_OUTPUT)) return 0;
+        nrm = node;  nmul = m;  i_nmul = i + 1;  i_lgt = i + 2;
+        i = i + 2;
+        node = t;
+    }
     if (node->op == GGML_OP_MUL_MAT && node->src[0]->type == GGML_TYPE_F32 && node->src[1]->type == GGML_TYPE_F32 && node->type == GGML_TYPE_F32 && node->ne[0] <= 64 &&
         node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 && !GGML_MI355X_FUSE_OFF() && !getenv("GGML_MI355X_ROUTER_LOGITS_OFF")) {
         int j = i + 1;
@@ -1724,6 +1739,8 @@ int graph_pass::site_moe_router(int i, ggml_tensor * node, int gop) {
         lgt = node;
         i = j;
         node = cgraph->nodes[j];
+    } else if (nrm) {
+        return 0;
     }
     if (node->op == GGML_OP_SOFT_MAX && !node->src[1] && node->ne[0] <= 64 && node->ne[2] == 1 && node->ne[3] == 1 && !GGML_MI355X_FUSE_OFF()) {
         // the MoE router behind its logits (build_moe_ffn): soft_max -> argsort (top_k view) -> get_rows -> sum_rows -> div
@@ -1765,6 +1782,27 @@ int graph_pass::site_moe_router(int i, ggml_tensor * node, int gop) {
                 if (!early_write_ok(as, { node->src[0], lgt ? lgt->src[1] : nullptr, lgt ? lgt->src[0] : nullptr }, node->src[0])) return 0;
                 if (!(can_hoist(dv, skipped) && early_write_ok(dv, { node->src[0], as, lgt ? lgt->src[1] : nullptr, lgt ? lgt->src[0] : nullptr })) && !hoist_elsewhere(ctx, dv)) return 0;
                 const qmm_tensor lg = to_qt(node->src[0], ctx), ids = to_qt(as, ctx), w = to_qt(dv, ctx);
+                if (nrm) {
+                    // the normed row is written where the MUL would put it, two nodes early and beside this launch's reads of the un-normed
+                    // rows (in place over them is fine: a workgroup holds its row in registers before it stores) and of the weights; the
+                    // router's outputs stay clear of all of them
+                    const ggml_tensor * x0 = nrm->src[0];
+                    if (!(early_write_ok(nmul, { nwgt, lgt->src[0] }) && early_write_ok(nmul, { x0 }, x0))) return 0;
+                    if (!early_write_ok(lgt, { x0, nwgt, nmul, lgt->src[0] }) || !early_write_ok(as, { x0, nwgt, nmul }) ||
+                        (to_qt(dv, ctx).data == dv->data && !early_write_ok(dv, { x0, nwgt, nmul }))) return 0;
+                    const qmm_tensor gi = to_qt(lgt->src[0], ctx), xin = to_qt(x0, ctx), nw = to_qt(nwgt, ctx), ny = to_qt(nmul, ctx);
+                    float eps;
+                    memcpy(&eps, nrm->op_params, sizeof(float));
+                    if (!is_ours(lgt->src[0]) || is_split(lgt->src[0]) || !qmm_moe_router_logits_norm_supported(&gi, &xin, &nw, &ny, &lg, &ids, &w, n_used)) return 0;
+                    if (qmm_moe_router_logits_norm(ctx->dev->qmm, &gi, &xin, &nw, eps, &ny, &lg, &ids, &w, n_used, 1, qmm_stream(ctx->dev->qmm))) {
+                        GGML_LOG_ERROR("MI355X MoE router with norm and logits(%s): %s\n", node->name, qmm_last_error());
+                        return -1;
+                    }
+                    if (dbg()) fprintf(stderr, "fused: moe router (%s) with its logits (%s) and their norm (%s)\n", node->name, lgt->name, nmul->name);
+                    done[i_nmul] = done[i_lgt] = done[i] = 1;                   // mul, logits, soft_max; the caller entered with the norm
+                    for (int j = 0; j < 4; ++j) done[idx[j]] = 1;
+                    return 1;
+                }
                 if (lgt) {
                     const qmm_tensor gi = to_qt(lgt->src[0], ctx), xin = to_qt(lgt->src[1], ctx);
                     if (!is_ours(lgt->src[0]) || is_split(lgt->src[0]) || !qmm_moe_router_logits_supported(&gi, &xin, &lg, &ids, &w, n_used)) return 0;

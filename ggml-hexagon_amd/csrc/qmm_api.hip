@@ -57,32 +57,38 @@ static int launch_matvec_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, c
     return QMM_OK;
 }
 
+// (q80: the group holds Q8_0 matrices too; no fused norm, N <= 4: mul_mat_group_impl)
 template <int NTOK>
-static int launch_kmix_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K) {
-    const size_t lds = kmix_lds_bytes(NTOK, K) + (g.norm_w ? (size_t) NTOK * K * 4 : 0);
+static int launch_kmix_n(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K, bool q80 = false) {
+    const size_t lds = kmix_lds_bytes(NTOK, K) + (g.norm_w ? (size_t) NTOK * K * 4 : 0) + (q80 ? matvec_lds_bytes<T_Q8_0P, NTOK>(K) : 0);
     if (lds > 160 * 1024) return fail(QMM_EUNSUPPORTED, "mixed-type matvec: %d tokens x K=%d needs %zu B of LDS", NTOK, K, lds);
     auto kern = group_has_extras(g) ? matvec_kmix_kernel<NTOK, true> : matvec_kmix_kernel<NTOK, false>;
+    if constexpr (NTOK <= 4) {
+        if (q80) kern = group_has_extras(g) ? matvec_kmix_kernel<NTOK, true, true> : matvec_kmix_kernel<NTOK, false, true>;
+    } else if (q80) {
+        return fail(QMM_EUNSUPPORTED, "mixed-format matvec: up to 4 tokens");
+    }
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     const int total = g.row_end[g.n - 1];
     int nw = (total + c->cus - 1) / c->cus;
     nw = nw > 8 ? 16 : nw > 4 ? 8 : 4;
     int blocks = (total + nw - 1) / nw;
     if (blocks > c->cus * c->mv_bpc) blocks = c->cus * c->mv_bpc;
-    QMM_TRACE(c, "matvec_kmix_kernel<%d,%s>", NTOK, group_has_extras(g) ? "true" : "false");
+    QMM_TRACE(c, q80 ? "matvec_kmix_kernel<%d,%s,q8_0>" : "matvec_kmix_kernel<%d,%s>", NTOK, group_has_extras(g) ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * WAVE), lds, st, g, x, ldx, K, c->act_mode | (c->mv_onepass ? 0 : 256), total);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }
-static int launch_kmix(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K, int N) {
+static int launch_kmix(qmm_ctx * c, hipStream_t st, const MatvecGroup & g, const float * x, int64_t ldx, int K, int N, bool q80 = false) {
     switch (N) {
-        case 1: return launch_kmix_n<1>(c, st, g, x, ldx, K);
-        case 2: return launch_kmix_n<2>(c, st, g, x, ldx, K);
-        case 3: return launch_kmix_n<3>(c, st, g, x, ldx, K);
-        case 4: return launch_kmix_n<4>(c, st, g, x, ldx, K);
-        case 5: return launch_kmix_n<5>(c, st, g, x, ldx, K);
-        case 6: return launch_kmix_n<6>(c, st, g, x, ldx, K);
-        case 7: return launch_kmix_n<7>(c, st, g, x, ldx, K);
-        case 8: return launch_kmix_n<8>(c, st, g, x, ldx, K);
+        case 1: return launch_kmix_n<1>(c, st, g, x, ldx, K, q80);
+        case 2: return launch_kmix_n<2>(c, st, g, x, ldx, K, q80);
+        case 3: return launch_kmix_n<3>(c, st, g, x, ldx, K, q80);
+        case 4: return launch_kmix_n<4>(c, st, g, x, ldx, K, q80);
+        case 5: return launch_kmix_n<5>(c, st, g, x, ldx, K, q80);
+        case 6: return launch_kmix_n<6>(c, st, g, x, ldx, K, q80);
+        case 7: return launch_kmix_n<7>(c, st, g, x, ldx, K, q80);
+        case 8: return launch_kmix_n<8>(c, st, g, x, ldx, K, q80);
         default: return fail(QMM_EINVAL, "kmix matvec: N=%d", N);
     }
 }
@@ -298,7 +304,7 @@ qmm_ctx * qmm_create(int device) {
     if (e) c->splitk = atoi(e);
     e = getenv("GGML_MI355X_ACT_MODE");
     if (e) c->act_mode = atoi(e) ? QMM_ACT_X86 : QMM_ACT_REF;
-    e = getenv("GGML_MI355X_MV_KMIX");
+    e = getenv("GGML_MI355X_MV_KMIX");      // 0: off, 1: K-quant groups only, 2 (default): also groups with Q8_0 matrices
     if (e) c->mv_kmix = atoi(e);
     e = getenv("GGML_MI355X_WIDE");
     if (e) c->wide = atoi(e);
@@ -665,10 +671,17 @@ static int mul_mat_group_impl(qmm_ctx * c, const qmm_weight * ws, int nw, int64_
     if (N <= QMM_MATVEC_MAX_N && nw >= 2 && nw <= MV_MAX_GROUP && c->mv_kmix) {
         // K-quant matrices of different types share the Q8_K activations: one mixed-type launch for the whole group
         bool kq = true, mixed = false;
+        int n_k = 0, n_80 = 0;                                    // K-quant matrices (Q8_K activations), Q8_0 matrices (Q8_0 activations)
         for (int i = 0; i < nw; ++i) {
-            kq = kq && (ws[i].type == T_Q4_K || ws[i].type == T_Q5_K || ws[i].type == T_Q6_K || ws[i].type == T_Q6_KP) && ws[i].M > 0;
+            const bool k = ws[i].type == T_Q4_K || ws[i].type == T_Q5_K || ws[i].type == T_Q6_K || ws[i].type == T_Q6_KP;
+            const bool q = ws[i].type == T_Q8_0 || ws[i].type == T_Q8_0P;
+            n_k += k;  n_80 += q;
+            kq = kq && (k || q) && ws[i].M > 0;
             mixed = mixed || ws[i].type != ws[0].type;
         }
+        // both activation formats in one group (Mixtral's q in Q4_K with k / v in Q8_0): one launch that stages the row twice
+        const bool q80 = n_80 > 0;
+        if (q80) kq = kq && n_k > 0 && c->mv_kmix > 1 && N <= 4 && !norm_w && !(ex && ex->swiglu) && (size_t) N * K * 21 / 8 + 4096 <= 150 * 1024;
         if (kq && mixed && (size_t) N * K * 11 / 8 + 4096 <= 150 * 1024) {
             MatvecGroup g;
             memset(&g, 0, sizeof(g));
@@ -682,7 +695,7 @@ static int mul_mat_group_impl(qmm_ctx * c, const qmm_weight * ws, int nw, int64_
             }
             g.n = nw;
             extras(g, idx, 0);
-            return launch_kmix(c, st, g, x, ldx, (int) K, (int) N);
+            return launch_kmix(c, st, g, x, ldx, (int) K, (int) N, q80);
         }
     }
     if (N <= QMM_MATVEC_MAX_N) {

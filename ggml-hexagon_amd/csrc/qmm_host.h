@@ -22,7 +22,7 @@ struct qmm_ctx {
     int         act_mode = QMM_ACT_REF;
     int         prec = QMM_PREC_F16_Q8;
     int         mv_bpc = 1;          // mat-vec blocks per CU (tuning knob, GGML_MI355X_MV_BPC)
-    int         mv_kmix = 1;         // one mixed-type mat-vec launch for K-quant groups of different types (GGML_MI355X_MV_KMIX=0: off)
+    int         mv_kmix = 2;         // one mixed-type mat-vec launch for K-quant groups of different types (GGML_MI355X_MV_KMIX=0: off; 1: not for groups that also hold Q8_0 matrices)
     int         mm_group = 1;        // prefill: one tiled launch for same-type matrices that share src1 (GGML_MI355X_MM_GROUP=0: off)
     int         skinny = 1;          // few-token split-K MFMA kernel (GGML_MI355X_SKINNY=0 turns it off)
     int         skinny_max_n = 64;   // ... used for 8 < N <= this, and up to skinny_max_n_few when the matrix has no more

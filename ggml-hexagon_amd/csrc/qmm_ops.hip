@@ -723,15 +723,49 @@ moe_router_kernel(const char * __restrict__ logits, char * __restrict__ ids, cha
 // bit; wave 0 then routes the row from LDS.  (First version: four groups of 256, two rounds for Mixtral's eight experts: the launch
 // then took as long as the two it replaced, gpu_ms_per_token 2.94 -> 2.93.)
 __device__ __forceinline__ float dot_f32_share(const float * __restrict__ pa, const float * __restrict__ pb, const int K, const int t);
+// NORM (round 3): x is the un-normed row; the workgroup forms rms_norm(x) * norm_w itself (rms_norm_vec_kernel<true, false, 1024>'s arithmetic and order of
+// additions, so the bits of the separate launch), stores it to `normed` for the expert MUL_MAT_IDs and dots the logits against the copy in LDS:
+// build_moe_ffn's ffn_norm launch (4.75 us of a Mixtral layer's ~84) disappears.  K <= 16384, K % 4 == 0, 16-byte aligned rows.
+template <bool NORM>
 __global__ void __launch_bounds__(1024)
 moe_router_logits_kernel(const char * __restrict__ wgt, const char * __restrict__ x, char * __restrict__ logits, char * __restrict__ ids,
                          char * __restrict__ weights, const int64_t a_nb1, const int64_t b_nb1, const int64_t l_nb1, const int64_t i_nb1, const int64_t w_nb1,
-                         const int K, const int n_expert, const int n_used, const int normalise) {
+                         const int K, const int n_expert, const int n_used, const int normalise,
+                         const float * __restrict__ norm_w = nullptr, const float eps = 0.0f, char * __restrict__ normed = nullptr, const int64_t y_nb1 = 0) {
     constexpr int NG = 1024 / DOT_T, WPG = DOT_T / 64;     // groups per workgroup (experts side by side), waves per group
-    __shared__ float red[16];
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    __shared__ float red[17];
     __shared__ float lg[64];
     const int n = blockIdx.x, tid = threadIdx.x, grp = tid / DOT_T, tg = tid % DOT_T, lane = tid & 63, wg = (tid >> 6) % WPG;
     const float * pb = (const float *) (x + (int64_t) n * b_nb1);
+    if (NORM) {
+        const float4 * px = (const float4 *) pb;
+        float4 *       py = (float4 *) (normed + (int64_t) n * y_nb1);
+        const uint32_t n4 = (uint32_t) K / 4;
+        float4 v[4], wv[4];
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = tid + j * 1024;
+            v[j]  = i < n4 ? px[i] : make_float4(0, 0, 0, 0);
+            wv[j] = i < n4 ? ((const float4 *) norm_w)[i] : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        const float scale = rms_scale_block<1024>(sum, red, (float) K, eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = tid + j * 1024;
+            if (i < n4) {
+                float4 r = make_float4(v[j].x * scale, v[j].y * scale, v[j].z * scale, v[j].w * scale);
+                r.x *= wv[j].x; r.y *= wv[j].y; r.z *= wv[j].z; r.w *= wv[j].w;
+                py[i] = r;
+                ((float4 *) xs)[i] = r;
+            }
+        }
+        __syncthreads();
+        pb = xs;
+    }
     for (int e0 = 0; e0 < n_expert; e0 += NG) {              // uniform trip count: every thread meets every barrier
         const int e = e0 + grp, ec = e < n_expert ? e : n_expert - 1;
         float s = dot_f32_share((const float *) (wgt + (int64_t) ec * a_nb1), pb, K, tg);
@@ -2330,9 +2364,34 @@ int qmm_moe_router_logits(qmm_ctx * ctx, const qmm_tensor * gate_inp, const qmm_
         return fail(QMM_EUNSUPPORTED, "qmm_moe_router_logits: operands not supported");
     HIP_TRY(hipSetDevice(ctx->device));
     QMM_CHAIN_FLUSH(ctx);
-    hipLaunchKernelGGL(moe_router_logits_kernel, dim3((unsigned) x->ne[1]), dim3(1024), 0, ctx->s(stream), (const char *) gate_inp->data, (const char *) x->data,
+    hipLaunchKernelGGL(moe_router_logits_kernel<false>, dim3((unsigned) x->ne[1]), dim3(1024), 0, ctx->s(stream), (const char *) gate_inp->data, (const char *) x->data,
                        (char *) logits->data, (char *) ids->data, (char *) weights->data, gate_inp->nb[1], x->nb[1], logits->nb[1], ids->nb[1], (int64_t) n_used * 4,
-                       (int) gate_inp->ne[0], (int) logits->ne[0], (int) n_used, normalise);
+                       (int) gate_inp->ne[0], (int) logits->ne[0], (int) n_used, normalise, nullptr, 0.0f, nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    return QMM_OK;
+}
+
+int qmm_moe_router_logits_norm_supported(const qmm_tensor * gate_inp, const qmm_tensor * x, const qmm_tensor * norm_w, const qmm_tensor * normed,
+                                         const qmm_tensor * logits, const qmm_tensor * ids, const qmm_tensor * weights, int64_t n_used) {
+    if (!norm_w || !normed || !qmm_moe_router_logits_supported(gate_inp, x, logits, ids, weights, n_used)) return 0;
+    const int64_t K = x->ne[0];
+    if (norm_w->type != G_F32 || normed->type != G_F32 || K % 4 || K > 16384) return 0;
+    if (norm_w->ne[0] != K || norm_w->ne[1] * norm_w->ne[2] * norm_w->ne[3] != 1 || norm_w->nb[0] != 4) return 0;
+    for (int i = 0; i < 4; ++i) if (normed->ne[i] != x->ne[i]) return 0;
+    if (normed->nb[0] != 4 || x->nb[1] % 16 || normed->nb[1] % 16 || gate_inp->nb[1] % 16) return 0;
+    return (uintptr_t) x->data % 16 == 0 && (uintptr_t) normed->data % 16 == 0 && (uintptr_t) norm_w->data % 16 == 0 && (uintptr_t) gate_inp->data % 16 == 0;
+}
+
+int qmm_moe_router_logits_norm(qmm_ctx * ctx, const qmm_tensor * gate_inp, const qmm_tensor * x, const qmm_tensor * norm_w, float eps, const qmm_tensor * normed,
+                               const qmm_tensor * logits, const qmm_tensor * ids, const qmm_tensor * weights, int64_t n_used, int normalise, void * stream) {
+    if (!ctx || eps < 0.0f || !qmm_moe_router_logits_norm_supported(gate_inp, x, norm_w, normed, logits, ids, weights, n_used))
+        return fail(QMM_EUNSUPPORTED, "qmm_moe_router_logits_norm: operands not supported");
+    HIP_TRY(hipSetDevice(ctx->device));
+    QMM_CHAIN_FLUSH(ctx);
+    hipLaunchKernelGGL(moe_router_logits_kernel<true>, dim3((unsigned) x->ne[1]), dim3(1024), (size_t) x->ne[0] * 4, ctx->s(stream), (const char *) gate_inp->data,
+                       (const char *) x->data, (char *) logits->data, (char *) ids->data, (char *) weights->data, gate_inp->nb[1], x->nb[1], logits->nb[1], ids->nb[1],
+                       (int64_t) n_used * 4, (int) gate_inp->ne[0], (int) logits->ne[0], (int) n_used, normalise, (const float *) norm_w->data, eps,
+                       (char *) normed->data, normed->nb[1]);
     HIP_TRY(hipGetLastError());
     return QMM_OK;
 }

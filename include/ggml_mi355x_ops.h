@@ -110,6 +110,14 @@ QMM_API int qmm_moe_router_logits_supported(const qmm_tensor * gate_inp, const q
                                             const qmm_tensor * weights, int64_t n_used);
 QMM_API int qmm_moe_router_logits(qmm_ctx * ctx, const qmm_tensor * gate_inp, const qmm_tensor * x, const qmm_tensor * logits, const qmm_tensor * ids,
                                   const qmm_tensor * weights, int64_t n_used, int normalise, void * stream);
+/* ... and with the RMS norm in front of it (build_moe_ffn's input is ffn_norm = rms_norm(ffn_inp) * w, src/llama-model.cpp:4301-4305): `x` is the
+ * un-normed row [K <= 16384, n_tokens <= 8], `normed` receives rms_norm(x, eps) * norm_w with the bits qmm_op(RMS_NORM_MUL) gives (the expert
+ * MUL_MAT_IDs read it), the logits are taken against it.  `normed` may be `x` itself (same rows) and nothing else that overlaps it. */
+QMM_API int qmm_moe_router_logits_norm_supported(const qmm_tensor * gate_inp, const qmm_tensor * x, const qmm_tensor * norm_w, const qmm_tensor * normed,
+                                                 const qmm_tensor * logits, const qmm_tensor * ids, const qmm_tensor * weights, int64_t n_used);
+QMM_API int qmm_moe_router_logits_norm(qmm_ctx * ctx, const qmm_tensor * gate_inp, const qmm_tensor * x, const qmm_tensor * norm_w, float eps,
+                                       const qmm_tensor * normed, const qmm_tensor * logits, const qmm_tensor * ids, const qmm_tensor * weights,
+                                       int64_t n_used, int normalise, void * stream);
 
 /* The other end of the block: out [E, n_tokens] = sum over the used experts of x [E, n_used, n_tokens] * w [1, n_used, n_tokens]
  * (ggml_mul by the router weights, then the ggml_add chain over 2-D views, src/llama-graph.cpp:896-911), in the graph's order. */

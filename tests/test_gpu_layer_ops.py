@@ -381,6 +381,45 @@ def test_moe_router_with_its_logits_one_launch(qmm, n_tok, n_expert, n_used, k):
     assert np.allclose(outs[1][0].cpu().numpy(), want, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("n_tok,n_expert,n_used,k,in_place", [(1, 8, 2, 4096, False), (1, 8, 2, 4096, True), (4, 8, 2, 4096, False), (2, 16, 4, 5120, True), (8, 64, 6, 16384, False)])
+def test_moe_router_with_norm_and_logits_one_launch(qmm, n_tok, n_expert, n_used, k, in_place):
+    """qmm_moe_router_logits_norm (round 3): ffn_norm = rms_norm(x) * w, the router's logits against it, soft_max, argsort and the top-k
+    weights in ONE launch, against the three launches it replaces (qmm_op RMS_NORM_MUL, qmm_op MUL_MAT on F32, qmm_moe_router): the
+    same bits in the normed row and in all three router outputs; also with the normed row written over x (ggml-alloc's in-place mul)"""
+    import struct
+    from ggml_hexagon_amd import capi
+    rng = np.random.default_rng(n_tok * 11 + n_expert + k)
+    gi = dev(rng.normal(0, 0.05, (n_expert, k)).astype(np.float32))
+    x0 = rng.normal(0, 1.5, (n_tok, k)).astype(np.float32)
+    nw = dev(rng.uniform(0.5, 1.5, (k,)).astype(np.float32))
+    eps = 1e-5
+    eps_bits = struct.unpack("<i", struct.pack("<f", eps))[0]
+    M = capi.QmmTensor.make
+    r = lambda t: capi.C.byref(t)
+    outs = []
+    for fused in (False, True):
+        x = dev(x0)
+        y = x if in_place else torch.full((n_tok, k), float("nan"), device="cuda")
+        lg = torch.full((n_tok, n_expert), float("nan"), device="cuda")
+        ids = torch.full((n_tok, n_expert), -1, dtype=torch.int32, device="cuda")
+        w = torch.zeros((n_tok, n_used), device="cuda")
+        tg, tx, tn = M(F32, [k, n_expert], data=gi.data_ptr()), M(F32, [k, n_tok], data=x.data_ptr()), M(F32, [k], data=nw.data_ptr())
+        ty = M(F32, [k, n_tok], data=y.data_ptr(), op_params=(eps_bits,))
+        tl, ti, tw = M(F32, [n_expert, n_tok], data=lg.data_ptr()), M(I32, [n_expert, n_tok], data=ids.data_ptr()), M(F32, [n_used, n_tok], data=w.data_ptr())
+        if fused:
+            assert qmm.lib.qmm_moe_router_logits_norm_supported(r(tg), r(tx), r(tn), r(ty), r(tl), r(ti), r(tw), n_used)
+            qmm._chk(qmm.lib.qmm_moe_router_logits_norm(qmm.ctx, r(tg), r(tx), r(tn), eps, r(ty), r(tl), r(ti), r(tw), n_used, 1, qmm._stream()))
+        else:
+            qmm._chk(qmm.lib.qmm_op_compute(qmm.ctx, capi.OP_RMS_NORM_MUL, r(tx), r(tn), None, r(ty), qmm._stream()))
+            qmm._chk(qmm.lib.qmm_op_compute(qmm.ctx, QMM_OP_MUL_MAT_F, r(tg), r(ty), None, r(tl), qmm._stream()))
+            qmm._chk(qmm.lib.qmm_moe_router(qmm.ctx, r(tl), r(ti), r(tw), n_used, 1, qmm._stream()))
+        qmm.synchronize()
+        outs.append((y.clone(), lg, ids, w))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert np.allclose(outs[1][0].cpu().numpy(), rms_norm(x0, nw.cpu().numpy(), eps), rtol=2e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("n_tok,n_used,e", [(1, 2, 4096), (70, 2, 1024), (5, 6, 512)])
 def test_moe_combine_one_launch(qmm, n_tok, n_used, e):
     """experts * weights and the sum over the used experts (build_moe_ffn's tail) in one launch, in place over slice 0 as ggml-alloc

@@ -211,6 +211,29 @@ def test_mixed_type_group_one_launch(qmm, oracle, n):
             assert torch.equal(o, qmm.mul_mat(t, wd, k, dev(x)))
 
 
+@pytest.mark.parametrize("n", [1, 2, 4, 5])
+def test_mixed_format_group_one_launch(qmm, oracle, n):
+    """round 3: K-quant matrices and Q8_0 matrices sharing src1 (Mixtral's attn_q in Q4_K beside attn_k / attn_v in Q8_0) go out as ONE
+    launch that stages the row as Q8_K and as Q8_0 (up to 4 tokens; 5: the per-type launches): every matrix against the oracle and
+    bit-identical to its own single launch; wire and planar Q8_0 rows, ragged row counts, K = 14336"""
+    import ggml_hexagon_amd.synth as synth
+    for k, spec in ((4096, ((Q4_K, 300), (Q8_0, 70), (Q8_0, 130))), (1024, ((Q8_0, 64), (Q6_K, 33), (Q4_K, 1), (Q8_0, 257))), (14336, ((Q8_0, 96), (Q5_K, 160)))):
+        ws_np = [(t, synth.synth_weights(t, m, k, seed=m + t, sigma=0.25)) for t, m in spec]
+        x = np.random.default_rng(k + n).uniform(-1, 1, (n, k)).astype(np.float32)
+        for planar in (False, True):
+            ws = []
+            for t, w in ws_np:
+                wd = dev(w)
+                tt = qmm.repack_rows(t, wd, k, True) if planar and t == Q8_0 and qmm.planar_type(t, k, wd.stride(-2)) else t
+                ws.append((tt, wd))
+            outs = [torch.full((n, w.shape[0]), 3.0, device="cuda") for _, w in ws]
+            labels = qmm.trace(lambda: qmm.mul_mat_group(ws, k, dev(x), outs))
+            assert (len(labels) == 1 and "q8_0" in labels[0]) == (n <= 4 and n * k * 21 // 8 + 4096 <= 150 * 1024), labels      # (both staged rows must fit LDS)
+            for (t, w), (tt, wd), o in zip(ws_np, ws, outs):
+                assert rel_rms(o.cpu().numpy(), oracle.mul_mat(t, w, k, x, ACT_REF)) < 2e-5, (TYPE_NAMES[t], k, n)
+                assert torch.equal(o, qmm.mul_mat(tt, wd, k, dev(x)))
+
+
 @pytest.mark.parametrize("t", ALL, ids=IDS)
 def test_prefill_group_one_tiled_launch(qmm, oracle, t):
     """same-type matrices sharing src1 at prefill batch sizes go out as ONE tiled launch (+ one split-K reduce): every
