@@ -51,7 +51,12 @@ def test_every_kernel_is_bit_identical_on_planar_rows(qmm, t, k, n):
     want = qmm.mul_mat(t, w, k, x)
     tp = qmm.repack_rows(t, w, k, True)
     got = qmm.mul_mat(tp, w, k, x)
-    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    if t == Q4_0 and n <= 8:
+        # round 3: the planar Q4_0 mat-vec unit holds two blocks per lane (MvUnit<T_Q4_0P>): the same exact block products, summed over
+        # the lanes in another f32 order than the wire rows' one-block unit
+        assert float((got - want).norm() / want.norm()) < 1e-6
+    else:
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
 
 
 def test_mixed_group_with_planar_q6k(qmm):
@@ -79,7 +84,11 @@ def test_mul_mat_id_on_planar_experts(qmm):
             want = qmm.mul_mat_id(t, w, k, b, ids[:, :n_used])
             wp = w.clone()
             tp = qmm.repack_rows(t, wp, k, True)
-            assert torch.equal(qmm.mul_mat_id(tp, wp, k, b, ids[:, :n_used]), want)
+            got = qmm.mul_mat_id(tp, wp, k, b, ids[:, :n_used])
+            if t == Q4_0 and n_tokens == 1:                     # (the mat-vec form: two blocks per lane on planar rows, see above)
+                assert float((got - want).norm() / want.norm()) < 1e-6
+            else:
+                assert torch.equal(got, want)
     qmm.synchronize()
 
 
