@@ -489,12 +489,39 @@ cpy_transpose_kernel(const char * __restrict__ x, char * __restrict__ y, const u
 //   rope(q) -> f32            rope(k) -> the f16 K cache (ggml_rope_ext + ggml_cpy(k_cur, k_cache_view))
 //   v       -> the f16 (transposed) V cache (ggml_cpy(v_cur^T, v_cache_view))
 // The grid is the concatenation of the three index spaces; k and v parts are optional (nk = 0 / nv = 0).
+// the same for ROPE_HC heads of one (pair, token): cos / sin (the double-precision reduction and two polynomials, ~150 instructions) once for
+// all of them; round 3: one thread per (pair, head, token) made the 512-token launch ALU-bound at 14.5 us for 22 MB of traffic
+constexpr uint32_t ROPE_HC = 8;
+template <typename TD>
+__device__ __forceinline__ void rope_pair_heads(const char * __restrict__ x, const int32_t * __restrict__ pos, const float * __restrict__ ff,
+                                                char * __restrict__ y, const Shape & sx, const Shape & sy, const RopeParams & rp, const uint32_t gid) {
+    const uint32_t half = (uint32_t) sx.ne[0] / 2, ne1 = (uint32_t) sx.ne[1], nch = (ne1 + ROPE_HC - 1) / ROPE_HC;
+    const uint32_t p = gid % half;
+    uint32_t c1, i2, i3;
+    row_coords(gid / half, nch, (uint32_t) sx.ne[2], c1, i2, i3);
+    const uint32_t i0 = 2 * p, h0 = c1 * ROPE_HC, h1 = h0 + ROPE_HC < ne1 ? h0 + ROPE_HC : ne1;
+    const bool pass = i0 >= (uint32_t) rp.n_dims;                // pass-through channels
+    float c = 1.0f, s = 0.0f;
+    if (!pass) rope_cs((float) pos[i2], p, rp, ff, c, s);
+    const uint32_t ia = pass || !rp.neox ? i0 : p, ib = pass || !rp.neox ? i0 + 1 : p + rp.n_dims / 2;
+    for (uint32_t i1 = h0; i1 < h1; ++i1) {
+        const float * px = (const float *) (x + i1 * sx.nb[1] + i2 * sx.nb[2] + i3 * sx.nb[3]);
+        TD *          py = (TD *) (y + i1 * sy.nb[1] + i2 * sy.nb[2] + i3 * sy.nb[3]);
+        const float x0 = px[ia], x1 = px[ib];
+        if (pass) { py[ia] = (TD) x0; py[ib] = (TD) x1; }
+        else      { py[ia] = (TD) (x0 * c - x1 * s); py[ib] = (TD) (x0 * s + x1 * c); }
+    }
+}
+__host__ __device__ inline uint32_t rope_heads_threads(const Shape & sx) {       // threads rope_pair_heads wants for a tensor
+    return (uint32_t) (sx.ne[0] / 2 * ((sx.ne[1] + ROPE_HC - 1) / ROPE_HC) * sx.ne[2] * sx.ne[3]);
+}
+
 struct RopeStoreArgs {
     const char * q; char * qd; const char * k; char * kd; const char * v; char * vd;
     const int32_t * pos; const float * ff;
     Shape sq, sqd, sk, skd, sv, svd;
     RopeParams rp;
-    uint32_t nq, nk, nv;          // pairs of q, pairs of k, elements of v
+    uint32_t nq, nk, nv;          // threads for q, for k (rope_heads_threads: a thread takes a pair of ROPE_HC heads), elements of v
 };
 // VT: the v part is a 2-D transpose (v_cur^T, dense along its dim 1, into rows of the transposed cache, dense along dim 0) and
 // large enough for 32 x 32 tiles through LDS: blocks behind the rope blocks take one tile each, reading along the source's dense
@@ -521,9 +548,9 @@ rope_store_kernel(const RopeStoreArgs g, const uint32_t pair_blocks, const uint3
         return;
     }
     uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    if (gid < g.nq) { rope_pair<float>(g.q, g.pos, g.ff, g.qd, g.sq, g.sqd, g.rp, gid); return; }
+    if (gid < g.nq) { rope_pair_heads<float>(g.q, g.pos, g.ff, g.qd, g.sq, g.sqd, g.rp, gid); return; }
     gid -= g.nq;
-    if (gid < g.nk) { rope_pair<__half>(g.k, g.pos, g.ff, g.kd, g.sk, g.skd, g.rp, gid); return; }
+    if (gid < g.nk) { rope_pair_heads<__half>(g.k, g.pos, g.ff, g.kd, g.sk, g.skd, g.rp, gid); return; }
     gid -= g.nk;
     if (!VT && gid < g.nv) st_from_f32<__half>(g.vd + elem_offset(gid, g.svd), ld_as_f32<float>(g.v + elem_offset(gid, g.sv)));
 }
@@ -2200,7 +2227,7 @@ int qmm_rope_kv_store(qmm_ctx * ctx, const qmm_tensor * q, const qmm_tensor * po
     g.v = v ? (const char *) v->data : nullptr; g.vd = v ? (char *) v_dst->data : nullptr; g.sv = shape_of(v ? v : q); g.svd = shape_of(v ? v_dst : q_dst);
     g.pos = (const int32_t *) pos->data; g.ff = ff ? (const float *) ff->data : nullptr;
     g.rp = rope_params(q_dst);
-    g.nq = (uint32_t) (nelements(q) / 2); g.nk = k ? (uint32_t) (nelements(k) / 2) : 0; g.nv = v ? (uint32_t) nelements(v) : 0;
+    g.nq = rope_heads_threads(g.sq); g.nk = k ? rope_heads_threads(g.sk) : 0; g.nv = v ? (uint32_t) nelements(v) : 0;
     const bool vt = v && v->ne[2] == 1 && v->ne[3] == 1 && v_dst->ne[2] == 1 && v_dst->ne[3] == 1 && v->ne[0] == v_dst->ne[0] && v->ne[1] == v_dst->ne[1] &&
                     v->nb[1] == 4 && v_dst->nb[0] == 2 && v->ne[0] >= 32 && v->ne[1] >= 32;
     if (vt) {
