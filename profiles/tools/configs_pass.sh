@@ -8,6 +8,9 @@ cd $ROOT
 for w in llama2-7b-q4_0 synth-7b-q4_k mixtral-8x7b-q4_k_m; do
   echo "== $w"; timeout -k 10 900 python3 bench.py --workload $w --no-cpu-baseline > $OUT/$w.json 2> $OUT/$w.err; echo rc=$?
 done
+for w in llama3-8b-q3_k_m llama3-8b-q2_k llama3-8b-iq4_xs; do      # not BASELINE configs: the other weight formats on the llama3-8b shapes
+  echo "== $w"; timeout -k 10 600 python3 bench.py --workload $w --no-cpu-baseline > $OUT/$w.json 2> $OUT/$w.err; echo rc=$?
+done
 echo "== llama3-70b-q4_k_m (one GPU, hot path only)"; timeout -k 10 900 python3 bench.py --workload llama3-70b-q4_k_m --no-cpu-baseline --no-e2e --steps 2 > $OUT/llama3-70b-q4_k_m.json 2> $OUT/llama3-70b-q4_k_m.err; echo rc=$?
 echo done
 echo "== rocprofv3 kernel trace of Mixtral token generation end to end"

@@ -24,7 +24,7 @@ echo "== in-kernel stamps: the Q4_K prefill kernel (three shapes), the decode at
 B=$ROOT/profiles/tools/_bin
 if [ -x $B/r64s_dev ]; then
   for a in "28672 4096 512 1" "4096 14336 512 8" "4096 4096 512 8" "6144 4096 512 4"; do echo "== r64s_dev $a"; R64S_VARIANT=2 timeout -k 10 120 $B/r64s_dev $a 3; done > $OUT/r64s_stamps.txt 2>&1
-  for n in 256 512 64; do echo "== attn_dev $n"; timeout -k 10 120 $B/attn_dev $n; done > $OUT/attn_decode_stamps.txt 2>&1
+  for n in 256 512 64 640 768 1016; do echo "== attn_dev $n"; timeout -k 10 120 $B/attn_dev $n; done > $OUT/attn_decode_stamps.txt 2>&1
   timeout -k 10 200 $B/nb4 > $OUT/nb4.log 2>&1
 fi
 echo "== SQ counters: the 64-rows-per-wave kernel compiler-scheduled and hand-placed, 28672 x 4096 x 512"

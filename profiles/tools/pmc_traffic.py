@@ -7,7 +7,9 @@ fetch_csv, write_csv, pop_json, tag = sys.argv[1], sys.argv[2], sys.argv[3], sys
 
 
 def norm(name):                     # "void qmm::matvec_kernel<12, 1, false>(qmm::MatvecGroup, ...)" -> "matvec_kernel<12,1,false>"
-    return re.sub(r"\(.*", "", name).replace("void ", "").replace("qmm::", "").replace(" ", "")
+    n = re.sub(r"\(.*", "", name).replace("void ", "").replace("qmm::", "").replace(" ", "")
+    # matvec_kmix_kernel's third template argument (the Q8_0 fields) is ",q8_0" in the library's trace labels, absent when false
+    return re.sub(r"(matvec_kmix_kernel<\d+,(?:true|false)),(true|false)>", lambda m: m.group(1) + (",q8_0>" if m.group(2) == "true" else ">"), n)
 
 
 def load(path, counter):

@@ -34,7 +34,7 @@ struct Config {
     const char * name;
     int n_layer, n_embd, n_ff, n_head, n_head_kv, n_vocab;
     float rope_base;
-    const char * recipe;     // q4_0 | q4_k | q4_k_m | q5_0 | q3_k_m | iq4_xs | mix
+    const char * recipe;     // q4_0 | q4_k | q4_k_m | q5_0 | q3_k_m | q2_k | iq4_xs | mix
     int n_expert, n_used;
 };
 static const Config CONFIGS[] = {
@@ -50,6 +50,7 @@ static const Config CONFIGS[] = {
     { "tiny-iq4_xs",        8, 1024,  2816,  8, 2,   4096,  10000.0f, "iq4_xs", 0, 0 },      // round 3 (8 layers: the first one's ffn_down is Q5_K, llama-quant.cpp:299)
     { "llama3-8b-iq4_xs",  32, 4096, 14336, 32, 8,  128256, 500000.0f, "iq4_xs", 0, 0 },
     { "llama3-8b-q3_k_m",  32, 4096, 14336, 32, 8,  128256, 500000.0f, "q3_k_m", 0, 0 },
+    { "llama3-8b-q2_k",    32, 4096, 14336, 32, 8,  128256, 500000.0f, "q2_k",   0, 0 },      // llama-quant.cpp:213-215, 272, 324: attn_v Q4_K (n_gqa >= 4), ffn_down / attn_output Q3_K
     { "llama2-7b-q4_0",    32, 4096, 11008, 32, 32,  32000, 10000.0f, "q4_0",   0, 0 },
     { "llama3-8b-q4_k_m",  32, 4096, 14336, 32, 8,  128256, 500000.0f, "q4_k_m", 0, 0 },
     { "synth-7b-q4_k",     32, 4096, 11008, 32, 32,  32000, 10000.0f, "q4_k",   0, 0 },
@@ -70,8 +71,8 @@ struct TensorSpec {
 static std::vector<TensorSpec> tensor_list(const Config & c) {
     std::vector<TensorSpec> ts;
     const bool q40 = !strcmp(c.recipe, "q4_0"), q4k = !strcmp(c.recipe, "q4_k"), q50 = !strcmp(c.recipe, "q5_0"), q3km = !strcmp(c.recipe, "q3_k_m"),
-               mix = !strcmp(c.recipe, "mix"), iq4xs = !strcmp(c.recipe, "iq4_xs");
-    const ggml_type base = q40 ? GGML_TYPE_Q4_0 : q50 ? GGML_TYPE_Q5_0 : q3km ? GGML_TYPE_Q3_K : mix ? GGML_TYPE_Q4_1 : iq4xs ? GGML_TYPE_IQ4_XS : GGML_TYPE_Q4_K;
+               mix = !strcmp(c.recipe, "mix"), iq4xs = !strcmp(c.recipe, "iq4_xs"), q2k = !strcmp(c.recipe, "q2_k");
+    const ggml_type base = q40 ? GGML_TYPE_Q4_0 : q50 ? GGML_TYPE_Q5_0 : q3km ? GGML_TYPE_Q3_K : mix ? GGML_TYPE_Q4_1 : iq4xs ? GGML_TYPE_IQ4_XS : q2k ? GGML_TYPE_Q2_K : GGML_TYPE_Q4_K;
     const int64_t kv = (int64_t) c.n_embd / c.n_head * c.n_head_kv;
     ts.push_back({ "token_embd.weight", base, { c.n_embd, c.n_vocab, 1 }, 2 });
     ts.push_back({ "output_norm.weight", GGML_TYPE_F32, { c.n_embd, 1, 1 }, 1 });
@@ -82,12 +83,15 @@ static std::vector<TensorSpec> tensor_list(const Config & c) {
             tv = i < 2 ? GGML_TYPE_Q5_K : GGML_TYPE_Q4_K;
             to = GGML_TYPE_Q4_K;
             td = i < c.n_layer / 16 ? GGML_TYPE_Q5_K : GGML_TYPE_Q4_K;
+        } else if (q2k) {
+            tv = c.n_head / c.n_head_kv >= 4 ? GGML_TYPE_Q4_K : GGML_TYPE_Q3_K;
+            to = td = GGML_TYPE_Q3_K;
         } else if (iq4xs) {                                   // llama-quant.cpp:232-234 (attn_v at n_gqa >= 4), :299-301 (ffn_down of the first eighth, no imatrix)
             if (c.n_head / c.n_head_kv >= 4) tv = GGML_TYPE_Q5_K;
             if (i < c.n_layer / 8) td = GGML_TYPE_Q5_K;
         } else if (mix) {
             tq = GGML_TYPE_Q4_1; tk = GGML_TYPE_Q5_1; tv = GGML_TYPE_IQ4_NL; to = GGML_TYPE_Q5_0; tg = GGML_TYPE_Q2_K; td = GGML_TYPE_Q3_K;
-        } else if (!q40 && !q4k && !q50 && !iq4xs) {
+        } else if (!q40 && !q4k && !q50 && !iq4xs && !q2k) {
             const bool more = use_more_bits(i, c.n_layer);
             tv = td = more ? GGML_TYPE_Q6_K : GGML_TYPE_Q4_K;
             if (c.n_layer >= 80 && tv == GGML_TYPE_Q4_K) tv = GGML_TYPE_Q5_K;
