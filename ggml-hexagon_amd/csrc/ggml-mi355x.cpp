@@ -1724,11 +1724,14 @@ int graph_pass::site_moe_router(int i, ggml_tensor * node, int gop) {
     int i_nmul = -1, i_lgt = -1;
     if (node->op == GGML_OP_RMS_NORM && i + 2 < n_nodes && node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 && single_use(node) && !GGML_MI355X_FUSE_OFF() &&
         !getenv("GGML_MI355X_ROUTER_NORM_OFF") && !getenv("GGML_MI355X_ROUTER_LOGITS_OFF")) {
-        ggml_tensor * m = cgraph->nodes[i + 1], * t = cgraph->nodes[i + 2];
-        if (done[i + 1] || done[i + 2] || fused_pair(node, m, &nwgt) != QMM_OP_RMS_NORM_MUL) return 0;
-        if (t->op != GGML_OP_MUL_MAT || t->src[1] != m || (m->flags & GGML_TENSOR_FLAG_OUTPUT)) return 0;
-        nrm = node;  nmul = m;  i_nmul = i + 1;  i_lgt = i + 2;
-        i = i + 2;
+        ggml_tensor * m = cgraph->nodes[i + 1];
+        int j2 = i + 2;                                                         // (the 3-D reshape of the normed row for the expert MUL_MAT_IDs sits in between)
+        while (j2 < n_nodes && (done[j2] || is_noop(cgraph->nodes[j2]))) ++j2;
+        if (j2 >= n_nodes || done[i + 1] || fused_pair(node, m, &nwgt) != QMM_OP_RMS_NORM_MUL) return 0;
+        ggml_tensor * t = cgraph->nodes[j2];
+        if (t->op != GGML_OP_MUL_MAT || t->src[1] != m || t->src[0]->type != GGML_TYPE_F32 || (m->flags & GGML_TENSOR_FLAG_OUTPUT)) return 0;
+        nrm = node;  nmul = m;  i_nmul = i + 1;  i_lgt = j2;
+        i = j2;
         node = t;
     }
     if (node->op == GGML_OP_MUL_MAT && node->src[0]->type == GGML_TYPE_F32 && node->src[1]->type == GGML_TYPE_F32 && node->type == GGML_TYPE_F32 && node->ne[0] <= 64 &&
@@ -1740,6 +1743,7 @@ int graph_pass::site_moe_router(int i, ggml_tensor * node, int gop) {
         i = j;
         node = cgraph->nodes[j];
     } else if (nrm) {
+        if (dbg()) fprintf(stderr, "fusion declined: moe router with its norm (%s): not the logits' MUL_MAT\n", nmul->name);
         return 0;
     }
     if (node->op == GGML_OP_SOFT_MAX && !node->src[1] && node->ne[0] <= 64 && node->ne[2] == 1 && node->ne[3] == 1 && !GGML_MI355X_FUSE_OFF()) {
@@ -1793,7 +1797,10 @@ int graph_pass::site_moe_router(int i, ggml_tensor * node, int gop) {
                     const qmm_tensor gi = to_qt(lgt->src[0], ctx), xin = to_qt(x0, ctx), nw = to_qt(nwgt, ctx), ny = to_qt(nmul, ctx);
                     float eps;
                     memcpy(&eps, nrm->op_params, sizeof(float));
-                    if (!is_ours(lgt->src[0]) || is_split(lgt->src[0]) || !qmm_moe_router_logits_norm_supported(&gi, &xin, &nw, &ny, &lg, &ids, &w, n_used)) return 0;
+                    if (!is_ours(lgt->src[0]) || is_split(lgt->src[0]) || !qmm_moe_router_logits_norm_supported(&gi, &xin, &nw, &ny, &lg, &ids, &w, n_used)) {
+                        if (dbg()) fprintf(stderr, "fusion declined: moe router with its norm (%s): operands not supported\n", nmul->name);
+                        return 0;
+                    }
                     if (qmm_moe_router_logits_norm(ctx->dev->qmm, &gi, &xin, &nw, eps, &ny, &lg, &ids, &w, n_used, 1, qmm_stream(ctx->dev->qmm))) {
                         GGML_LOG_ERROR("MI355X MoE router with norm and logits(%s): %s\n", node->name, qmm_last_error());
                         return -1;
