@@ -19,7 +19,7 @@ EXPORTS = [
     "qmm_memcpy_d2h", "qmm_memcpy_d2d", "qmm_memset", "qmm_synchronize", "qmm_memcpy2d_d2d", "qmm_event_create",
     "qmm_event_destroy", "qmm_event_record", "qmm_stream_wait_event", "qmm_event_synchronize", "qmm_event_create_timing", "qmm_event_elapsed_ms", "qmm_memcpy_h2d_async",
     "qmm_memcpy_d2h_async", "qmm_row_size", "qmm_planar_type", "qmm_repack_rows", "qmm_dequantize",
-    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_swiglu_in", "qmm_mul_mat_id", "qmm_mul_mat_id_pair", "qmm_mul_mat_id_swiglu_supported", "qmm_mul_mat_id_swiglu",
+    "qmm_quantize_act", "qmm_mul_mat", "qmm_mul_mat_group", "qmm_mul_mat_group_ex", "qmm_mul_mat_group_norm_supported", "qmm_mul_mat_swiglu_in", "qmm_mul_mat_id", "qmm_mul_mat_id_pair", "qmm_mul_mat_id_swiglu_supported", "qmm_mul_mat_id_swiglu",
     "qmm_chain_begin", "qmm_chain_flush", "qmm_chain_end", "qmm_chain_stats", "qmm_chain_debug", "qmm_trace_begin", "qmm_trace_end",
     "qmm_comm_create", "qmm_comm_destroy", "qmm_comm_size", "qmm_comm_broadcast", "qmm_comm_gather", "qmm_comm_all_gather",
 ]
@@ -31,7 +31,8 @@ OPS_EXPORTS = [
 
 
 class QmmMvExtra(C.Structure):
-    _fields_ = [("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("residual", C.c_void_p * 4), ("swiglu", C.c_int)]
+    _fields_ = [("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("residual", C.c_void_p * 4), ("swiglu", C.c_int),
+                ("norm_add", C.c_void_p), ("norm_add_ld", C.c_int64), ("norm_sum", C.c_void_p), ("norm_sum_ld", C.c_int64)]
 
 
 class QmmTensor(C.Structure):
@@ -277,8 +278,9 @@ class Qmm:
             return keep[2]
         return call
 
-    def mul_mat_group_ex(self, weights, k, x, outs, norm_w=None, eps=0.0, residuals=None, swiglu=0):
-        """qmm_mul_mat_group_ex: x -> rms_norm(x, eps) * norm_w while staging (optional), outs[i] = W_i x + residuals[i] (optional)"""
+    def mul_mat_group_ex(self, weights, k, x, outs, norm_w=None, eps=0.0, residuals=None, swiglu=0, norm_add=None, norm_sum=None):
+        """qmm_mul_mat_group_ex: x -> rms_norm(x, eps) * norm_w while staging (optional), outs[i] = W_i x + residuals[i] (optional);
+        prompt batches: norm_add is added to x in front of the norm and norm_sum receives the sum"""
         arr = (QmmWeight * len(weights))()
         for i, ((t, w), o) in enumerate(zip(weights, outs)):
             arr[i] = QmmWeight(w.data_ptr(), w.stride(0), w.shape[0], o.data_ptr(), o.stride(0), t)
@@ -286,6 +288,10 @@ class Qmm:
         ex.norm_w = norm_w.data_ptr() if norm_w is not None else None
         ex.norm_eps = eps
         ex.swiglu = swiglu
+        if norm_add is not None:
+            ex.norm_add, ex.norm_add_ld = norm_add.data_ptr(), norm_add.stride(0)
+        if norm_sum is not None:
+            ex.norm_sum, ex.norm_sum_ld = norm_sum.data_ptr(), norm_sum.stride(0)
         for i in range(4):
             r = residuals[i] if residuals is not None and i < len(residuals) else None
             ex.residual[i] = r.data_ptr() if r is not None else None

@@ -105,7 +105,7 @@ struct mi355x_backend_ctx {
     // RMS_NORM -> MUL(w) held back for the MUL_MATs that read it (few-token batches): they form the normed row while staging
     struct swiglu_src { const float * gate = nullptr; const float * up = nullptr; int64_t ld_gate = 0, ld_up = 0; };
     std::vector<swiglu_src>          swiglu_in;      // per node: this ffn_down forms silu(gate) * up in its activation prep (prompt batches)
-    struct norm_req { const ggml_tensor * rn = nullptr, * mul = nullptr, * w = nullptr; int readers = 0; };
+    struct norm_req { const ggml_tensor * rn = nullptr, * mul = nullptr, * w = nullptr; int readers = 0; const ggml_tensor * add = nullptr; };   // add: the residual ADD in front of the norm (prompt batches)
     norm_req                         pending_norm;
     // GGML_MI355X_TIMING=1: stream time of every graph (an event pair around its launches), summed per kind of graph
     qmm_event *                      ev_t0 = nullptr, * ev_t1 = nullptr;
@@ -952,7 +952,35 @@ enum ggml_status compute_mul_mat(mi355x_backend_ctx * ctx, ggml_tensor * const *
             bool norm_in_kernel = n == pn.readers;
             for (int i = 0; norm_in_kernel && i < n; ++i)
                 norm_in_kernel = !bytes_overlap(ws[i].dst, (size_t) ((N - 1) * ws[i].ldd + ws[i].M) * sizeof(float), to_qt(pn.rn->src[0], ctx).data, ggml_nbytes(pn.rn->src[0]));
-            if (norm_in_kernel) {
+            if (pn.add) {
+                // a prompt batch (site_add_rms_norm held ADD -> RMS_NORM -> MUL back): the group's activation prep adds, norms and stores the
+                // sum.  The products are written by later launches of the same stream, so they may sit on the dead operands; not on the sum
+                const ggml_tensor * x0 = pn.add->src[0], * x1 = pn.add->src[1];
+                norm_in_kernel = n == pn.readers && qmm_mul_mat_group_norm_supported(q, ws, n, K, N);
+                for (int i = 0; norm_in_kernel && i < n; ++i)
+                    norm_in_kernel = !bytes_overlap(ws[i].dst, (size_t) ((N - 1) * ws[i].ldd + ws[i].M) * sizeof(float), to_qt(pn.add, ctx).data, ggml_nbytes(pn.add));
+                if (norm_in_kernel) {
+                    x = (const float *) to_qt(x0, ctx).data;
+                    ldx = x0->nb[1] / sizeof(float);
+                    ex.norm_w = (const float *) pn.w->data;
+                    memcpy(&ex.norm_eps, pn.rn->op_params, sizeof(float));
+                    ex.norm_add = (const float *) to_qt(x1, ctx).data;
+                    ex.norm_add_ld = x1->nb[1] / sizeof(float);
+                    ex.norm_sum = (float *) to_qt(pn.add, ctx).data;
+                    ex.norm_sum_ld = pn.add->nb[1] / sizeof(float);
+                    use_ex = true;
+                    if (dbg()) fprintf(stderr, "fused: add + norm (%s) into the prep of %s\n", pn.add->name, dst->name);
+                } else {                                                              // the graph's three nodes after all, as the site would have run them
+                    const qmm_tensor a = to_qt(x0, ctx), bb = to_qt(x1, ctx), w = to_qt(pn.w, ctx), sum = to_qt(pn.add, ctx), d = to_qt(pn.mul, ctx);
+                    float eps;
+                    memcpy(&eps, pn.rn->op_params, sizeof(float));
+                    if (dbg()) fprintf(stderr, "fusion declined: add + norm (%s) into the prep of %s (group of %d of %d readers)\n", pn.add->name, dst->name, n, pn.readers);
+                    if (qmm_op_add_rms_norm(q, &a, &bb, &w, &sum, &d, eps, st)) {
+                        GGML_LOG_ERROR("MI355X ADD+RMS_NORM(%s): %s\n", pn.add->name, qmm_last_error());
+                        return GGML_STATUS_FAILED;
+                    }
+                }
+            } else if (norm_in_kernel) {
                 const qmm_tensor qx = to_qt(pn.rn->src[0], ctx);
                 x = (const float *) qx.data;
                 ldx = pn.rn->src[0]->nb[1] / sizeof(float);
@@ -1524,6 +1552,38 @@ int graph_pass::site_add_rms_norm(int i, ggml_tensor * node, int gop) {
         ggml_tensor * rn = cgraph->nodes[i + 1], * mul = cgraph->nodes[i + 2];
         if (rn->op == GGML_OP_RMS_NORM && rn->src[0] == node && single_use(rn) && fused_pair(rn, mul, &other) == QMM_OP_RMS_NORM_MUL) {
             const qmm_tensor a = to_qt(node->src[0], ctx), b = to_qt(node->src[1], ctx), w = to_qt(other, ctx), sum = to_qt(node, ctx), d = to_qt(mul, ctx);
+            // A prompt batch whose normed rows are read by ONE group of quantized MUL_MATs right behind the MUL (q / k / v, gate / up) and by
+            // nothing else: no launch here; the group's activation prep adds, norms and stores the sum (compute_mul_mat; round 3)
+            if (node->ne[1] > QMM_MATVEC_MAX_N && node->ne[2] == 1 && node->ne[3] == 1 && ggml_are_same_shape(node->src[0], node->src[1]) &&
+                ggml_are_same_shape(node, node->src[0]) && !getenv("GGML_MI355X_PREP_NORM_OFF")) {
+                const auto * ri = info(mul);
+                int found = 0, first = -1;
+                qmm_weight gw[4];
+                for (int j = i + 3; j < n_nodes && j <= i + 3 + LOOKAHEAD && ri && found < 4; ++j) {
+                    const ggml_tensor * t = cgraph->nodes[j];
+                    if (done[j] || is_noop(t)) continue;
+                    if (t->op == GGML_OP_MUL_MAT && !glue_op(t) && t->src[1] == mul && supports_mul_mat(t) && is_ours(t->src[0]) && !is_split(t->src[0]) &&
+                        t->src[0]->ne[2] == 1 && t->src[0]->ne[3] == 1) {
+                        if (first < 0) first = j;
+                        gw[found++] = qmm_weight{ t->src[0]->data, (int64_t) t->src[0]->nb[1], t->src[0]->ne[1], nullptr, 0, weight_type(ctx, t->src[0]) };
+                    } else if (first < 0) {
+                        break;                                                         // something else reads or runs first: keep the graph's order
+                    }
+                }
+                const ggml_tensor * x0 = node->src[0], * x1 = node->src[1];
+                if (ri && found >= 1 && found == ri->uses && !(mul->flags & GGML_TENSOR_FLAG_OUTPUT) && !(node->flags & GGML_TENSOR_FLAG_OUTPUT) &&
+                    x0->type == GGML_TYPE_F32 && x1->type == GGML_TYPE_F32 && x0->nb[0] == 4 && x1->nb[0] == 4 && node->nb[0] == 4 &&
+                    x0->nb[1] % 16 == 0 && x1->nb[1] % 16 == 0 && node->nb[1] % 16 == 0 && (uintptr_t) a.data % 16 == 0 && (uintptr_t) b.data % 16 == 0 &&
+                    (uintptr_t) sum.data % 16 == 0 && (uintptr_t) other->data % 16 == 0 &&
+                    // the sum is stored while other rows of the operands are still read: in place over an operand only with the same rows
+                    early_write_ok(node, { x0 }, x0) && early_write_ok(node, { x1 }, x1) && early_write_ok(node, { other }) &&
+                    qmm_mul_mat_group_norm_supported(ctx->dev->qmm, gw, found, node->ne[0], node->ne[1])) {
+                    ctx->pending_norm = { rn, mul, other, found, node };
+                    done[i + 1] = done[i + 2] = 1;
+                    if (dbg()) fprintf(stderr, "held back: add + norm (%s, %s) for the prep of %d MUL_MATs\n", node->name, mul->name, found);
+                    return 1;
+                }
+            }
             // `mul`'s buffer is written two nodes early: it may be the block of an ADD operand that dies here (same rows: fine, a
             // workgroup holds its row in registers before it stores; anything else: keep the graph's order)
             const bool e_ok = early_write_ok(mul, { node->src[0], node->src[1], other, node }, nullptr) ||

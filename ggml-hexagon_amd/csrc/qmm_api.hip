@@ -827,8 +827,34 @@ int qmm_mul_mat_group(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, con
     return mul_mat_group_impl(c, ws, nw, K, x, N, ldx, stream, nullptr);
 }
 
+int qmm_mul_mat_group_norm_supported(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, int64_t N) {
+    if (!c || !ws || nw < 1 || nw > MV_MAX_GROUP || N <= QMM_MATVEC_MAX_N || K <= 0 || K % 1024 || K > 16384) return 0;
+    if (c->prec != QMM_PREC_F16_Q8 || !c->prep_reg) return 0;
+    for (int i = 0; i < nw; ++i) {
+        const int t = type_base(ws[i].type);
+        if (!type_known(ws[i].type) || type_act(t) != T_Q8_K || t == T_IQ4_XS || !mfma_regb_supports(c, t)) return 0;
+    }
+    return 1;
+}
+
 int qmm_mul_mat_group_ex(qmm_ctx * c, const qmm_weight * ws, int nw, int64_t K, const float * x, int64_t N, int64_t ldx, const qmm_mv_extra * ex,
                          void * stream) {
+    if (c && ex && N > QMM_MATVEC_MAX_N) {
+        // a prompt batch: only the norm in front of the group (the activation prep forms it); everything else is the few-token kernels'
+        if (!ex->norm_w || ex->swiglu || ex->residual[0] || ex->residual[1] || ex->residual[2] || ex->residual[3])
+            return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_group_ex: batches of more than %d tokens take the norm only", QMM_MATVEC_MAX_N);
+        if (!qmm_mul_mat_group_norm_supported(c, ws, nw, K, N)) return fail(QMM_EUNSUPPORTED, "qmm_mul_mat_group_ex: this group does not take a fused norm at %lld tokens", (long long) N);
+        if (ex->norm_eps < 0.0f || (uintptr_t) ex->norm_w % 16 || (uintptr_t) x % 16 || ldx % 4 || (ex->norm_add && ((uintptr_t) ex->norm_add % 16 || ex->norm_add_ld % 4 || !ex->norm_sum)) ||
+            (ex->norm_sum && ((uintptr_t) ex->norm_sum % 16 || ex->norm_sum_ld % 4)))
+            return fail(QMM_EINVAL, "qmm_mul_mat_group_ex: norm operands must be 16-byte aligned rows, eps >= 0, a sum buffer with norm_add");
+        c->prep_norm = qmm_ctx::prep_norm_t{};
+        c->prep_norm.w = ex->norm_w;  c->prep_norm.eps = ex->norm_eps;
+        c->prep_norm.add = ex->norm_add;  c->prep_norm.ld_add = ex->norm_add_ld;
+        c->prep_norm.sum = ex->norm_add ? ex->norm_sum : nullptr;  c->prep_norm.ld_sum = ex->norm_sum_ld;
+        const int rc = mul_mat_group_impl(c, ws, nw, K, x, N, ldx, stream, nullptr);
+        c->prep_norm = qmm_ctx::prep_norm_t{};
+        return rc;
+    }
     return mul_mat_group_impl(c, ws, nw, K, x, N, ldx, stream, ex);
 }
 

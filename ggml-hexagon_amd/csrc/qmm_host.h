@@ -45,6 +45,10 @@ struct qmm_ctx {
     int *       flag = nullptr;      // device word set by kernels that meet an expert id out of range
     const float * prep_x2 = nullptr; // transient: second operand of a SwiGLU input while qmm_mul_mat_swiglu_in runs (prefill prep)
     int64_t     prep_ldx2 = 0;
+    // transient: while qmm_mul_mat_group_ex runs a prefill group with extra->norm_w, the activation prep forms rms_norm(x [+ add]) * w itself
+    // (prep_act_q8k_kernel<..., NORM>); behind the first prep of the call x is the stored sum, read as it is
+    struct prep_norm_t { const float * w = nullptr; float eps = 0.0f; const float * add = nullptr; int64_t ld_add = 0; float * sum = nullptr; int64_t ld_sum = 0;
+                         const float * x_over = nullptr; int64_t ld_over = 0; } prep_norm;
     int64_t     id_calls = 0, id_checked = 0;       // MUL_MAT_ID launches issued / covered by the last look at `flag` (qmm_synchronize reads the word only behind such a launch: a blocking 4-byte copy per synchronize cost llama.cpp's token loop ~70 us per token)
     int64_t     mfma_calls = 0, mfma_checked = 0;   // prefill calls issued / covered by the last non-finite check (qmm_synchronize)
     bool        wide_attr_set = false;

@@ -173,10 +173,20 @@ typedef struct qmm_mv_extra {
     float         norm_eps;
     const float * residual[4];
     int           swiglu;
+    /* prompt batches (N > 8, round 3; qmm_mul_mat_group_norm_supported): with norm_w the activation prep forms rms_norm(x [+ norm_add]) * norm_w
+     * itself; norm_add [N rows, norm_add_ld floats apart] is the residual the graph adds in front of the norm, norm_sum (may be NULL only
+     * without norm_add) receives x + norm_add.  norm_sum may be x or norm_add itself (same rows), nothing else that overlaps them. */
+    const float * norm_add;
+    int64_t       norm_add_ld;
+    float *       norm_sum;
+    int64_t       norm_sum_ld;
 } qmm_mv_extra;
 
 QMM_API int qmm_mul_mat_group_ex(qmm_ctx * ctx, const qmm_weight * ws, int n_weights, int64_t K,
                                  const float * x, int64_t N, int64_t ldx, const qmm_mv_extra * extra, void * stream);
+/* 1 when qmm_mul_mat_group_ex takes this group with extra->norm_w at N > 8 tokens: every matrix in a K-quant format whose prefill kernel
+ * takes the register-resident Q8_K prep (Q2_K ... Q6_K), K a multiple of 1024 up to 16384, the default precision mode. */
+QMM_API int qmm_mul_mat_group_norm_supported(qmm_ctx * ctx, const qmm_weight * ws, int n_weights, int64_t K, int64_t N);
 
 /* Chains: a run of DEPENDENT one-token MUL_MAT groups as one persistent launch (token generation: wo -> ffn_gate/up -> ffn_down ->
  * the next layer's wq/wk/wv have nothing between them once the norm, the residual add and the SwiGLU are folded in, and every

@@ -82,6 +82,44 @@ def test_mat_vec_with_norm_and_residual(qmm, oracle, n):
         assert rel_rms(acc[0].cpu().numpy(), oracle.mul_mat(ws_np[0][0], ws_np[0][1], k, x, ACT_REF) + res[0]) < 2e-5
 
 
+@pytest.mark.parametrize("n", [33, 200, 512])
+def test_prefill_group_with_residual_add_and_norm(qmm, oracle, n):
+    """qmm_mul_mat_group_ex at prompt batch sizes (round 3): the activation prep forms rms_norm(x + add) * w itself and stores x + add; against
+    the launches it replaces (the add, the norm, then the plain group): the sum bit for bit, the products within the prefill bar of each
+    other and of the oracle fed with the numpy-normed rows.  A same-type group, q / k / v with a Q6_K matrix (one prep for both operand
+    orders' shared bytes), Q5_K + Q3_K, without the add, the sum stored over x (ggml-alloc's in-place add)"""
+    import ggml_hexagon_amd.synth as synth
+    from oracle.pyoracle import Q3_K, Q5_K
+    rng = np.random.default_rng(300 + n)
+    for k, spec, with_add, in_place in ((4096, ((Q4_K, 320), (Q4_K, 64)), True, False), (4096, ((Q4_K, 256), (Q4_K, 96), (Q6_K, 128)), True, True),
+                                        (2048, ((Q5_K, 130), (Q3_K, 70)), True, False), (1024, ((Q4_K, 200),), False, False)):
+        x0 = rng.normal(0, 1.5, (n, k)).astype(np.float32)
+        b0 = rng.normal(0, 1.0, (n, k)).astype(np.float32)
+        w = rng.normal(1, 0.1, k).astype(np.float32)
+        eps = 1e-5
+        ws_np = [(t, synth.synth_weights(t, m, k, seed=m + t, sigma=0.25)) for t, m in spec]
+        ws = [(t, dev(a)) for t, a in ws_np]
+        x, b, dw = dev(x0), dev(b0), dev(w)
+        s_fused = x if in_place else torch.full((n, k), float("nan"), device="cuda")
+        outs = [torch.zeros((n, a.shape[0]), device="cuda") for _, a in ws_np]
+        labels = qmm.trace(lambda: qmm.mul_mat_group_ex(ws, k, x, outs, norm_w=dw, eps=eps, norm_add=b if with_add else None, norm_sum=s_fused if with_add else None))
+        assert any("norm" in l for l in labels) and not any(l.startswith("prep_act_q8k_kernel<") and "norm" not in l for l in labels), labels
+        # the launches it replaces
+        x2 = dev(x0)
+        xs = x2 + b if with_add else x2
+        xn = torch.from_numpy(rms_norm(xs.cpu().numpy(), w, eps)).cuda()
+        want = [torch.zeros((n, a.shape[0]), device="cuda") for _, a in ws_np]
+        qmm.mul_mat_group(ws, k, xn, want)
+        if with_add:
+            assert torch.equal(s_fused.view(torch.int32), xs.view(torch.int32))
+        for (t, a), o, wv in zip(ws_np, outs, want):
+            ref = oracle.mul_mat(t, a, k, xn.cpu().numpy(), ACT_REF)
+            rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+            assert float(np.linalg.norm(o.cpu().numpy() - ref) / np.linalg.norm(ref)) < 1e-3, (TYPE_NAMES[t], k, n)
+            # (the two norms differ in the last bit here and there; such a row quantizes one activation differently: 1 / 127 of one of K terms)
+            assert float((o - wv).abs().max()) / rms < 2.5e-3 * (4096 / k) ** 0.5, (TYPE_NAMES[t], k, n)
+
+
 @pytest.mark.parametrize("n", [1, 4, 8])
 def test_mat_vec_swiglu_pairs(qmm, oracle, n):
     """qmm_mul_mat_group_ex with swiglu: ffn_gate and ffn_up as row pairs, dst = silu(Wg x) * (Wu x), either order, with and
